@@ -1,0 +1,56 @@
+"""Input recipes shared by make_golden.py (which feeds them to the reference)
+and by the tests (which feed them to the oracle / the HIP path).  Pure
+functions of tspo_amd.synth - nothing here touches the reference."""
+import numpy as np
+import torch
+
+from tspo_amd import synth
+
+# (name, T, D, H, window, tau, M text rows, k list)
+SELECTOR_CASES = [
+    ("s32", 32, 64, 8, 12, 0.025, 1, [1, 6, 8, 16, 32, 37]),
+    ("s50", 50, 64, 8, 8, 0.01, 1, [1, 6, 8, 16, 32, 50, 55]),
+    ("s7", 7, 64, 8, 12, 0.025, 1, [1, 3, 7, 12]),
+    ("s40m3", 40, 64, 8, 7, 0.025, 3, [4, 16]),
+    ("s1", 1, 64, 8, 12, 0.025, 1, [1, 4]),
+    ("s1024", 1024, 768, 8, 12, 0.025, 1, [1, 8, 32, 64]),
+    ("s300", 300, 768, 8, 12, 0.02, 1, [16, 64]),
+]
+
+# (name, T, k, G, logit scale)
+GUMBEL_CASES = [("g64", 64, 6, 4, 3.0), ("g1024", 1024, 32, 8, 8.0), ("g512", 512, 16, 8, 40.0), ("g9", 9, 9, 2, 1.0)]
+
+# (name, T, D, H, window, tau, k, G)
+TRAIN_CASES = [("t48", 48, 64, 8, 12, 0.025, 6, 4), ("t512", 512, 768, 8, 12, 0.02, 16, 8)]
+
+CLIP_MID = dict(hidden=128, layers=3, heads=2, mlp=256, patch=14, image=224, proj=64)   # 257 tokens, head_dim 64
+CLIP_CASES = [("clip_tiny", synth.CLIP_TINY, 3), ("clip_mid", CLIP_MID, 2), ("clip_l14", synth.CLIP_L14, 2)]
+
+
+def selector_inputs(name, T, D, M):
+    seed = sum(ord(c) for c in name) * 13
+    img = synth.normal((T, D), seed + 1)
+    txt = synth.normal((M, D), seed + 2)
+    clip = torch.nn.CosineSimilarity(dim=-1)(torch.from_numpy(txt[:1]), torch.from_numpy(img)).numpy().astype(np.float32)
+    # std ~0.2 weights so the attention / MLP branch matters next to the residual
+    state = synth.selector_state(D, seed=seed % 97 + 3, std=0.2 / np.sqrt(D / 64), bias_std=0.1)
+    return img, txt, clip, state
+
+
+def gumbel_logits(T, scale):
+    return synth.normal((T,), 500 + T, scale)
+
+
+def train_inputs(name, T, D, G):
+    img, txt, clip, state = selector_inputs(name, T, D, 1)
+    if D == 768:
+        state = synth.selector_state(D, seed=41, std=0.02, bias_std=0.0)   # HF init: N(0,.02), zero bias
+    rewards = ((synth.uniform((G,), 77 + T) > 0.5).astype(np.float32) + synth.uniform((G,), 78 + T).astype(np.float32))
+    return img, txt, clip, state, rewards
+
+
+def clip_pixels(cfg, n_frames):
+    u8 = synth.uniform_u8((n_frames, 3, cfg["image"], cfg["image"]), 1234)
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], np.float32).reshape(1, 3, 1, 1)
+    return u8, ((u8.astype(np.float32) / 255.0 - mean) / std).astype(np.float32)
