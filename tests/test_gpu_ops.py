@@ -1,0 +1,286 @@
+"""GPU parity tests: every C-ABI entry point (through tspo_amd.ops) against the
+oracle and the golden vectors generated from the reference.  Integer outputs
+are compared bit-exactly; floating-point tolerances are written at each check."""
+import numpy as np
+import pytest
+import torch
+
+from inputs import (SELECTOR_CASES, GUMBEL_CASES, TRAIN_CASES, CLIP_CASES, selector_inputs, gumbel_logits,
+                    train_inputs, clip_pixels)
+from oracle import tspo_oracle as O
+from tspo_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T_(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def G_(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def flat_from_state(state, D):
+    offs = ops.flat_offsets(D)
+    flat = torch.zeros(offs["__total__"][0], dtype=torch.float32)
+    for name, (off, shape) in offs.items():
+        if name.startswith("__"):
+            continue
+        flat[off:off + int(np.prod(shape))] = T_(state[name]).flatten()
+    return flat.to(DEV)
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", SELECTOR_CASES, ids=[c[0] for c in SELECTOR_CASES])
+def test_topk_binmax_golden(golden, case):
+    name, T, D, H, w, tau, M, ks = case
+    g = golden["selector"]
+    s = G_(g[f"{name}.scores"])
+    for k in ks:
+        np.testing.assert_array_equal(ops.topk_sorted(s, k).cpu().numpy(), g[f"{name}.topk{k}"])
+        np.testing.assert_array_equal(ops.binmax(s, k).cpu().numpy(), g[f"{name}.binmax{k}"])
+
+
+def test_topk_ties_and_batch(golden):
+    s = G_(golden["misc"]["ties.scores"])
+    assert ops.topk_sorted(s, 3).tolist() == [1, 2, 4]
+    assert ops.topk_sorted(s, 5).tolist() == [0, 1, 2, 4, 6]
+    assert ops.topk_sorted(torch.zeros(100, device=DEV), 7).tolist() == list(range(7))
+    for T, k, B in [(4096, 64, 5), (16384, 1000, 2), (1000, 1000, 3), (1, 1, 2), (777, 33, 9)]:
+        x = synth.normal((B, T), 31 + T)
+        x[:, ::7] = np.round(x[:, ::7], 1)          # plenty of exact ties
+        got = ops.topk_sorted(G_(x), k).cpu()
+        for b in range(B):
+            np.testing.assert_array_equal(got[b].numpy(), O.topk_sorted(T_(x[b]), k).numpy())
+        gb = ops.binmax(G_(x), k).cpu()
+        for b in range(B):
+            np.testing.assert_array_equal(gb[b].numpy(), O.binmax(T_(x[b]), k).numpy())
+    x = synth.normal((64,), 5)
+    x[10] = np.nan
+    assert 10 in ops.topk_sorted(G_(x), 1).tolist()     # NaN ranks as the maximum (torch.topk)
+    x[3], x[40] = np.inf, -np.inf
+    np.testing.assert_array_equal(ops.topk_sorted(G_(x), 5).cpu().numpy(), O.topk_sorted(T_(x), 5).numpy())
+
+
+@pytest.mark.parametrize("case", GUMBEL_CASES, ids=[c[0] for c in GUMBEL_CASES])
+def test_gumbel_topk_injected_noise(golden, case):
+    name, T, k, G, scale = case
+    g = golden["gumbel"]
+    logits = gumbel_logits(T, scale)
+    out = ops.gumbel_topk(G_(logits[None]), k, G, noise=G_(g[f"{name}.noise"][None]), want_probs=True)
+    np.testing.assert_array_equal(out["idx"][0].cpu().numpy(), g[f"{name}.idx"])          # bit-exact
+    np.testing.assert_allclose(out["logp"][0].cpu().numpy(), g[f"{name}.logp"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(out["probs"][0].cpu().numpy(), g[f"{name}.probs"], rtol=0, atol=2e-6)
+
+
+def test_gumbel_topk_philox_and_batch():
+    B, G, T, k = 3, 5, 1024, 32
+    logits = synth.normal((B, T), 77, 4.0)
+    out = ops.gumbel_topk(G_(logits), k, G, seed=2024, offset=7, want_noise=True)
+    ref_noise = O.gumbel_noise_philox(B, G, T, 2024, 7)
+    noise = out["noise"].cpu().numpy()
+    np.testing.assert_allclose(noise, ref_noise, rtol=2e-5, atol=2e-5)      # same Philox bits, libm-level log differences
+    for b in range(B):
+        for g in range(G):
+            idx, _, lp = O.gumbel_topk(T_(logits[b]), T_(noise[b, g]), k)
+            np.testing.assert_array_equal(out["idx"][b, g].cpu().numpy(), idx.numpy())
+        np.testing.assert_allclose(out["logp"][b].cpu().numpy(), lp.numpy(), rtol=1e-5, atol=2e-5)
+    # different offset -> different stream; same (seed, offset) -> identical
+    o2 = ops.gumbel_topk(G_(logits), k, G, seed=2024, offset=7)
+    o3 = ops.gumbel_topk(G_(logits), k, G, seed=2024, offset=8)
+    assert torch.equal(o2["idx"], out["idx"]) and not torch.equal(o3["idx"], out["idx"])
+    with pytest.raises(RuntimeError):
+        ops.gumbel_topk(G_(logits[:, :8]), 9, 1)
+
+
+def test_advantage_and_pg_grad(golden):
+    g = golden["train"]
+    for nm in ("eq", "gen", "two", "bg"):
+        G = int(g[f"adv.{nm}.G"])
+        a = ops.grpo_advantage(G_(g[f"adv.{nm}.r"]).view(-1, G))
+        np.testing.assert_allclose(a.flatten().cpu().numpy(), g[f"adv.{nm}.a"], rtol=1e-5, atol=1e-6)
+    for name, T, D, H, w, tau, k, G in TRAIN_CASES:
+        scores, idx = g[f"{name}.scores"], g[f"{name}.idx"]
+        adv = ops.grpo_advantage(G_(g[f"{name}.rewards"][None]))
+        np.testing.assert_allclose(adv[0].cpu().numpy(), g[f"{name}.adv"], rtol=1e-5, atol=1e-6)
+        out = ops.gumbel_topk(G_(scores[None]), k, G, noise=G_(g[f"{name}.noise"][None]))
+        np.testing.assert_array_equal(out["idx"][0].cpu().numpy(), idx)
+        dl, loss = ops.pg_grad_logits(out["logp"], out["idx"], adv)
+        ref = g[f"{name}.dscores"]
+        np.testing.assert_allclose(dl[0].cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+        assert abs(loss[0].item() - float(g[f"{name}.loss"])) < 1e-5
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", SELECTOR_CASES, ids=[c[0] for c in SELECTOR_CASES])
+def test_selector_forward_golden(golden, case):
+    name, T, D, H, w, tau, M, ks = case
+    g = golden["selector"]
+    img, txt, clip, state = selector_inputs(name, T, D, M)
+    flat = flat_from_state(state, D)
+    s, h, _ = ops.selector_forward(flat, G_(img[None]), G_(txt[None]), G_(clip[None]), H, w, tau)
+    ref = g[f"{name}.scores"]
+    # fp32 MFMA (fmaf chains) vs CPU fp32; scores carry the 1/tau = 40..100x amplification
+    np.testing.assert_allclose(s[0].cpu().numpy(), ref, rtol=2e-5, atol=2e-5 / tau)
+    if f"{name}.attn" in g.files:
+        np.testing.assert_allclose(h.cpu().numpy(), g[f"{name}.attn"], rtol=1e-4, atol=2e-5)
+    else:
+        np.testing.assert_allclose(h[0, [0, 1, T // 2, T - 1]].cpu().numpy(), g[f"{name}.attn_rows"], rtol=1e-4, atol=5e-5)
+    # greedy top-k / bin-max of the HIP scores == the reference's indices wherever the reference's
+    # k-th / (k+1)-th gap exceeds the score tolerance
+    for k in ks:
+        srt = np.sort(ref)[::-1]
+        if k < T and srt[k - 1] - srt[k] < 1e-3 / tau * 0.025:
+            continue
+        np.testing.assert_array_equal(ops.topk_sorted(s[0], k).cpu().numpy(), g[f"{name}.topk{k}"])
+
+
+def test_selector_forward_batched_equals_single():
+    B, T, D, H, M, w, tau = 3, 130, 128, 8, 2, 12, 0.025
+    img, txt = synth.normal((B, T, D), 900), synth.normal((B, M, D), 901)
+    clip = synth.normal((B, T), 902, 0.1)
+    state = synth.selector_state(D, seed=5, std=0.1, bias_std=0.05)
+    flat = flat_from_state(state, D)
+    s, h, _ = ops.selector_forward(flat, G_(img), G_(txt), G_(clip), H, w, tau)
+    for b in range(B):
+        s1, h1, _ = ops.selector_forward(flat, G_(img[b:b + 1]), G_(txt[b:b + 1]), G_(clip[b:b + 1]), H, w, tau)
+        assert torch.equal(s1[0], s[b]) and torch.equal(h1[0], h[b])           # batching is bit-transparent
+        so, ho = O.selector_forward({k: T_(v) for k, v in state.items()}, T_(img[b]), T_(txt[b]), T_(clip[b]), w, tau, H)
+        np.testing.assert_allclose(s[b].cpu().numpy(), so.numpy(), rtol=2e-5, atol=1e-3)
+        np.testing.assert_allclose(h[b].cpu().numpy(), ho[0].numpy(), rtol=1e-4, atol=2e-5)
+    with pytest.raises(ValueError):
+        ops.selector_forward(flat, G_(img), G_(txt), G_(clip), H, 0, tau)      # window must be >= 1
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=[c[0] for c in TRAIN_CASES])
+def test_selector_backward_adamw_golden(golden, case):
+    name, T, D, H, w, tau, k, G = case
+    g = golden["train"]
+    img, txt, clip, state, rewards = train_inputs(name, T, D, G)
+    flat = flat_from_state(state, D)
+    s, _, ws = ops.selector_forward(flat, G_(img[None]), G_(txt[None]), G_(clip[None]), H, w, tau, want_attn=False)
+    np.testing.assert_allclose(s[0].cpu().numpy(), g[f"{name}.scores"], rtol=2e-5, atol=2e-5 / tau)
+    fg = torch.zeros_like(flat)
+    ops.selector_backward(flat, fg, G_(img[None]), G_(txt[None]), G_(g[f"{name}.dscores"][None]), H, w, tau, ws)
+    offs = ops.flat_offsets(D)
+    for pn in O.SELECTOR_KEYS:
+        off, shape = offs[pn]
+        got = fg[off:off + int(np.prod(shape))].cpu().numpy()
+        if "ffn_o" in pn:
+            assert np.all(got == 0)
+            continue
+        if f"{name}.grad.{pn}" in g.files:
+            ref = g[f"{name}.grad.{pn}"].flatten()
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+        else:
+            ref = g[f"{name}.gradsl.{pn}"]
+            np.testing.assert_allclose(got[:256], ref, rtol=2e-4, atol=2e-5 * max(np.abs(ref).max(), 1e-12))
+            sums = g[f"{name}.gradsum.{pn}"]
+            assert abs(np.abs(got.astype(np.float64)).sum() - sums[1]) <= 2e-4 * sums[1]
+            assert abs((got.astype(np.float64) ** 2).sum() - sums[2]) <= 5e-4 * sums[2]
+    n = ops.trainable_numel(D)
+    ns = ops.grad_norm_scale(fg, n, 1.0, 1.0)
+    tn = float(g[f"{name}.gradnorm"])
+    assert abs(ns[0].item() - tn) <= 2e-4 * tn
+    assert abs(ns[1].item() - O.clip_grad_scale(tn, 1.0)) <= 2e-4
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    ops.adamw_step(flat, fg, m, v, n, lr=5e-4, step=1, d_grad_scale=ns)
+    for pn in O.SELECTOR_KEYS:
+        if "ffn_o" in pn:
+            continue
+        off, shape = offs[pn]
+        np.testing.assert_allclose(flat[off:off + 256].cpu().numpy(), g[f"{name}.after.{pn}"], rtol=1e-4, atol=2e-6)
+
+
+def test_selector_backward_batched_sums():
+    """grads of a batch == sum of per-video grads (what the DP all-reduce relies on)."""
+    B, T, D, H, M, w, tau = 3, 96, 64, 8, 1, 12, 0.025
+    img, txt = synth.normal((B, T, D), 910), synth.normal((B, M, D), 911)
+    clip, ds = synth.normal((B, T), 912, 0.1), synth.normal((B, T), 913, 0.01)
+    flat = flat_from_state(synth.selector_state(D, seed=6, std=0.1, bias_std=0.05), D)
+    _, _, ws = ops.selector_forward(flat, G_(img), G_(txt), G_(clip), H, w, tau, want_attn=False)
+    gb = torch.zeros_like(flat)
+    ops.selector_backward(flat, gb, G_(img), G_(txt), G_(ds), H, w, tau, ws)
+    acc = torch.zeros_like(flat)
+    for b in range(B):
+        _, _, ws1 = ops.selector_forward(flat, G_(img[b:b + 1]), G_(txt[b:b + 1]), G_(clip[b:b + 1]), H, w, tau, want_attn=False)
+        g1 = torch.zeros_like(flat)
+        ops.selector_backward(flat, g1, G_(img[b:b + 1]), G_(txt[b:b + 1]), G_(ds[b:b + 1]), H, w, tau, ws1)
+        acc += g1
+    n = ops.trainable_numel(D)
+    np.testing.assert_allclose(gb[:n].cpu().numpy(), acc[:n].cpu().numpy(), rtol=1e-4, atol=1e-6 * acc.abs().max().item())
+
+
+# ---------------------------------------------------------------------------
+def _bf16r(x):
+    return torch.from_numpy(np.asarray(x)).float().to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (771, 3072, 1024), (64, 64, 640), (1, 768, 1024),
+                                   (1285, 1024, 4096)])
+def test_gemm_bf16(M, N, K):
+    A, W = _bf16r(synth.normal((M, K), 1 + M)), _bf16r(synth.normal((N, K), 2 + N, 0.05))
+    bias = T_(synth.normal((N,), 3, 0.1))
+    R = _bf16r(synth.normal((M, N), 4))
+    ref = A.float() @ W.float().t()                      # exact products of bf16 values, fp32 accumulation
+    tol = dict(rtol=1e-2, atol=2e-2)                      # bf16 output rounding (2^-8 relative)
+    out = ops.gemm_bf16(A.to(DEV), W.to(DEV), out_f32=True).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)       # fp32 out: accumulation order only
+    out = ops.gemm_bf16(A.to(DEV), W.to(DEV), bias=bias.to(DEV)).float().cpu()
+    np.testing.assert_allclose(out.numpy(), (ref + bias).numpy(), **tol)
+    out = ops.gemm_bf16(A.to(DEV), W.to(DEV), bias=bias.to(DEV), act=1).float().cpu()
+    np.testing.assert_allclose(out.numpy(), O.quick_gelu(ref + bias).numpy(), **tol)
+    out = ops.gemm_bf16(A.to(DEV), W.to(DEV), bias=bias.to(DEV), residual=R.to(DEV)).float().cpu()
+    np.testing.assert_allclose(out.numpy(), (ref + bias + R.float()).numpy(), **tol)
+
+
+def _clip_ref_bf16_weights(cfg, n):
+    """fp32 oracle evaluated with bf16-rounded matrices (what the encoder stores), fp32 activations."""
+    state = synth.clip_vision_state(**cfg)
+    w = {}
+    for k, v in state.items():
+        t = T_(v)
+        if v.ndim >= 2 and "position_embedding" not in k:
+            t = t.to(torch.bfloat16).float()
+        w[k] = t
+    u8, px = clip_pixels(cfg, n)
+    return state, u8, px, O.clip_vit_forward(w, T_(px), num_heads=cfg["heads"], patch=cfg["patch"])
+
+
+@pytest.mark.parametrize("case", [c for c in CLIP_CASES if c[0] != "clip_tiny"], ids=["clip_mid", "clip_l14"])
+def test_clip_vit_forward(golden, case):
+    tag, cfg, n = case
+    state, u8, px, ref_bw = _clip_ref_bf16_weights(cfg, n)
+    W = ops.ClipVitWeights({k: T_(v) for k, v in state.items()}, cfg, DEV)
+    feat = ops.clip_vit_forward(W, G_(px)).cpu().numpy()
+    gold = golden["clip"][f"{tag}.feat"]                 # transformers CLIP, fp32
+    scale = np.abs(gold).max()
+    err_g = np.abs(feat - gold).max() / scale
+    err_b = np.abs(feat - ref_bw.numpy()).max() / scale
+    cos = (feat * gold).sum(-1) / np.linalg.norm(feat, axis=-1) / np.linalg.norm(gold, axis=-1)
+    print(f"\n[{tag}] max|err|/max|ref|: vs fp32 golden {err_g:.4f}, vs bf16-weight oracle {err_b:.4f}, cos {cos.min():.6f}")
+    # bf16 activations through `layers` residual blocks: north-star tolerance for the encode = 3% of range, cos > 0.999
+    assert err_g < 3e-2 and err_b < 3e-2 and cos.min() > 0.999
+    # uint8 input with the normalisation fused into the patch gather gives the same features
+    f8 = ops.clip_vit_forward(W, G_(u8)).cpu().numpy()
+    assert np.abs(f8 - feat).max() / scale < 1e-2
+    # frames are independent: frame 1 alone == frame 1 in the batch (bitwise, same kernels / same order)
+    f1 = ops.clip_vit_forward(W, G_(px[1:2])).cpu().numpy()
+    np.testing.assert_array_equal(f1[0], feat[1])
+
+
+def test_clip_scores():
+    B, T, D = 2, 300, 768
+    txt, feat = synth.normal((B, 1, D), 41), synth.normal((B, T, D), 42)
+    got = ops.clip_scores(G_(txt), G_(feat)).cpu()
+    for b in range(B):
+        np.testing.assert_allclose(got[b].numpy(), O.clip_cosine_scores(T_(txt[b]), T_(feat[b])).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_ops_refuse_cpu_tensors():
+    from tspo_amd._lib import TspoHipError
+    with pytest.raises(TspoHipError):
+        ops.topk_sorted(torch.zeros(8), 2)

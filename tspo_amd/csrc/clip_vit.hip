@@ -1,0 +1,582 @@
+// CLIP ViT frame encoder for gfx950 (MI355X): bf16 MFMA GEMMs (fp32 accumulate)
+// with LDS-staged, XOR-swizzled tiles fed by global_load_lds (LDS-DMA), a
+// 257-token flash-style attention kernel that keeps the whole score row in
+// registers, wave-per-row LayerNorm and a fused patch gather (+u8 normalise).
+//
+// Replaces transformers' CLIPVisionTransformer + visual_projection as called
+// by the reference at model/temporal_agent.py:166, tspo_trainer.py:401.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint16_t bf16_t;
+
+namespace {
+
+// ===========================================================================
+// GEMM  C[M,N] = A[M,K] * W[N,K]^T  (both operands K-contiguous, bf16)
+// 128x128x64 workgroup tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32.
+// LDS image per operand tile: [128 rows][128 B], 16-B chunk c of row r stored
+// at chunk (c ^ (r & 7)) - the XOR is applied on the global SOURCE address of
+// the LDS-DMA (destination must stay lane-linear) and again on the ds_read.
+// The MFMA is issued "swapped" (A-operand = W fragment, B-operand = A fragment)
+// so that each lane ends up with 4 consecutive N for one M -> 8-byte stores.
+// ===========================================================================
+enum { GE_BIAS = 0, GE_GELU = 1, GE_RESID = 2, GE_F32 = 3, GE_PATCH = 4 };
+
+#define GT_BM 128
+#define GT_BN 128
+#define GT_BK 64
+#define GT_STAGE_BYTES (2 * 128 * 128)  // A tile + W tile, 16 KB each
+
+struct GemmArgs {
+  const bf16_t* A; const bf16_t* W; const float* bias; const bf16_t* R; void* C;
+  const float* pos;  // GE_PATCH: pos_emb [S, N]
+  int M, N, K, tilesN, nwg, P;  // P: patches per frame (GE_PATCH row remap)
+};
+
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int rows_total, int row0, int K, int kt,
+                                           char* lds_tile, int wid, int lane) {
+  // 16 pieces of 1 KB (8 rows x 128 B); wave `wid` issues pieces wid*4 .. wid*4+3
+  const int rin = lane >> 3, slot = lane & 7;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int piece = wid * 4 + p;
+    const int r = piece * 8 + rin;
+    int gr = row0 + r;
+    gr = gr < rows_total ? gr : rows_total - 1;
+    const int c = slot ^ (r & 7);
+    const bf16_t* src = G + (size_t)gr * K + (size_t)kt * GT_BK + c * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * GT_STAGE_BYTES];  // 2 stages x (A 16K | W 16K); the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  // XCD-aware, bijective remap: consecutive workgroups of one XCD walk the N tiles of one M row-panel
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = g.nwg >> 3, rr = g.nwg & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tm = wg / g.tilesN, tn = wg - tm * g.tilesN;
+  const int m0 = tm * GT_BM, n0 = tn * GT_BN;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int nk = g.K / GT_BK;
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage_tile(g.A, g.M, m0, g.K, 0, lds, wid, lane);
+  stage_tile(g.W, g.N, n0, g.K, 0, lds + 16384, wid, lane);
+
+  // per-lane read offsets (row-dependent swizzle is loop invariant)
+  int offA[4], offW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 64 + i * 16 + l15;
+    const int rw = wn * 64 + i * 16 + l15;
+    offA[i] = ra * 128;
+    offW[i] = 16384 + rw * 128;
+  }
+  const int sw = l15 & 7;  // (row & 7) == (l15 & 7) because every row base is a multiple of 16
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // stage kt landed (vmcnt(0) folded in by the compiler) and compute(kt-1) is done everywhere
+    char* cur = lds + (kt & 1) * GT_STAGE_BYTES;
+    if (kt + 1 < nk) {
+      char* nxt = lds + ((kt + 1) & 1) * GT_STAGE_BYTES;
+      stage_tile(g.A, g.M, m0, g.K, kt + 1, nxt, wid, lane);
+      stage_tile(g.W, g.N, n0, g.K, kt + 1, nxt + 16384, wid, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int co = (((kk * 4 + q4) ^ sw) << 4);
+      bf16x8 fa[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *reinterpret_cast<const bf16x8*>(cur + offA[i] + co);
+        fw[i] = *reinterpret_cast<const bf16x8*>(cur + offW[i] + co);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane holds n = nb + q4*4 + r (r = 0..3), m = mb + l15
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + l15;
+    if (m >= g.M) continue;
+    size_t orow = (size_t)m;
+    int prow = 0;
+    if (EPI == GE_PATCH) {
+      const int f = m / g.P;
+      prow = 1 + (m - f * g.P);
+      orow = (size_t)f * (g.P + 1) + prow;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + q4 * 4;
+      if (n >= g.N) continue;
+      f32x4 v = acc[ni][mi];
+      if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+        v += bv;
+      }
+      if (EPI == GE_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+      }
+      if (EPI == GE_PATCH) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
+        v += pv;
+      }
+      const size_t o = orow * g.N + n;
+      if (EPI == GE_RESID) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(g.R + o);
+        v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+        v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+      }
+      if (EPI == GE_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
+      } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + o) = pk;
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_gemm(GemmArgs g, hipStream_t st) {
+  const int tilesM = (g.M + GT_BM - 1) / GT_BM;
+  g.tilesN = (g.N + GT_BN - 1) / GT_BN;
+  g.nwg = tilesM * g.tilesN;
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(g.nwg), dim3(256), 0, st, g);
+  return tspo::check_launch("gemm_bf16");
+}
+
+int gemm_dispatch(int epi, const GemmArgs& g, hipStream_t st) {
+  switch (epi) {
+    case GE_BIAS: return launch_gemm<GE_BIAS>(g, st);
+    case GE_GELU: return launch_gemm<GE_GELU>(g, st);
+    case GE_RESID: return launch_gemm<GE_RESID>(g, st);
+    case GE_F32: return launch_gemm<GE_F32>(g, st);
+    case GE_PATCH: return launch_gemm<GE_PATCH>(g, st);
+  }
+  return tspo::set_err(TSPO_EINVAL, "gemm: bad epilogue %d", epi);
+}
+
+// ===========================================================================
+// LayerNorm over the last dim (C <= 4096, C % 8 == 0): one wave per row, the
+// row lives in registers (16-byte loads), two-pass mean / variance in fp32.
+// in_stride / out_stride in elements (lets the post-LN read only CLS rows).
+// ===========================================================================
+#define LN_MAXCH 8
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* in, bf16_t* out,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        long rows, int C, long in_stride, long out_stride, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* x = in + row * in_stride;
+  float v[LN_MAXCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXCH; ++c) {
+    const int e = (c * 64 + lane) * 8;
+    if (e < C) {
+      const uint4 u = *reinterpret_cast<const uint4*>(x + e);
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[c][2 * i] = bf16_to_f32((uint16_t)(w[i] & 0xffff));
+        v[c][2 * i + 1] = bf16_to_f32((uint16_t)(w[i] >> 16));
+        s += v[c][2 * i] + v[c][2 * i + 1];
+      }
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float qv = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXCH; ++c) {
+    const int e = (c * 64 + lane) * 8;
+    if (e < C) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; qv += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(qv) / (float)C + eps);
+  bf16_t* y = out + row * out_stride;
+#pragma unroll
+  for (int c = 0; c < LN_MAXCH; ++c) {
+    const int e = (c * 64 + lane) * 8;
+    if (e < C) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + e), g1 = *reinterpret_cast<const f32x4*>(gamma + e + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + e), b1 = *reinterpret_cast<const f32x4*>(beta + e + 4);
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = (v[c][i] - mean) * rstd * g0[i] + b0[i];
+        o[4 + i] = (v[c][4 + i] - mean) * rstd * g1[i] + b1[i];
+      }
+      uint4 u;
+      u.x = pack_bf16x2(o[0], o[1]); u.y = pack_bf16x2(o[2], o[3]);
+      u.z = pack_bf16x2(o[4], o[5]); u.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(y + e) = u;
+    }
+  }
+}
+
+// ===========================================================================
+// Patch gather (im2col for the stride-p conv) + CLS rows.
+// patches[(n*P + py*gw + px)][k = c*p*p + ky*p + kx] = pixel[n][c][py*p+ky][px*p+kx]
+// Kp = roundup(3*p*p, 64), padding zero.  TSPO_U8 input gets (x/255-mean)/std fused.
+// ===========================================================================
+template <typename TP>
+__device__ __forceinline__ float load_pixel(const TP* p, size_t i, int c);
+template <> __device__ __forceinline__ float load_pixel<float>(const float* p, size_t i, int) { return p[i]; }
+template <> __device__ __forceinline__ float load_pixel<bf16_t>(const bf16_t* p, size_t i, int) { return bf16_to_f32(p[i]); }
+template <> __device__ __forceinline__ float load_pixel<_Float16>(const _Float16* p, size_t i, int) { return (float)p[i]; }
+template <> __device__ __forceinline__ float load_pixel<uint8_t>(const uint8_t* p, size_t i, int c) {
+  const float mean = c == 0 ? 0.48145466f : (c == 1 ? 0.4578275f : 0.40821073f);
+  const float sd = c == 0 ? 0.26862954f : (c == 1 ? 0.26130258f : 0.27577711f);
+  return ((float)p[i] / 255.0f - mean) / sd;
+}
+
+template <typename TP>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const TP* __restrict__ px, bf16_t* __restrict__ out,
+                                                           int n_frames, int image, int patch, int Kp) {
+  const int gw = image / patch, P = gw * gw, pp = patch * patch, Kreal = 3 * pp;
+  const int oct = Kp / 8;
+  const size_t total = (size_t)n_frames * P * oct;
+  for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+    const int o8 = (int)(id % oct);
+    const size_t m = id / oct;
+    const int pidx = (int)(m % P);
+    const size_t n = m / P;
+    const int py = pidx / gw, pxx = pidx - py * gw;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = o8 * 8 + i;
+      if (k < Kreal) {
+        const int c = k / pp, rem = k - c * pp;
+        const int ky = rem / patch, kx = rem - ky * patch;
+        const size_t src = ((n * 3 + c) * image + (size_t)(py * patch + ky)) * image + (pxx * patch + kx);
+        v[i] = load_pixel<TP>(px, src, c);
+      } else {
+        v[i] = 0.f;
+      }
+    }
+    uint4 u;
+    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+    u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(out + m * Kp + (size_t)o8 * 8) = u;
+  }
+}
+
+// x[n*S + 0][:] = pos_emb[0][:]  (class_embedding already folded into row 0)
+__global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__ pos, bf16_t* __restrict__ x, int n_frames,
+                                                       int S, int C) {
+  const size_t total = (size_t)n_frames * C;
+  for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
+    const size_t n = id / C;
+    const int c = (int)(id - n * C);
+    x[n * S * C + c] = f32_to_bf16(pos[c]);
+  }
+}
+
+// ===========================================================================
+// Attention for one (frame, head): S <= 288 tokens, head_dim 64, non-causal.
+// K rows in LDS (swizzled like the GEMM tiles), V transposed in LDS (Vt[d][key],
+// 4-key groups XOR-swizzled by d>>3 so both the scattered b16 writes and the
+// b64 fragment reads spread over the banks).  Each wave owns 16-query tiles:
+//   S^T = K Q^T  (18 key tiles -> 72 fp32 regs hold the full score row)
+//   softmax over keys in registers (lane-local + 2 xor-shuffles)
+//   O^T = V^T P^T with P taken straight from the S^T accumulators (the key
+//   permutation inside each 32-key chunk is shared by both MFMA operands).
+// ===========================================================================
+#define AT_KEYS 288
+#define AT_VT_STRIDE 592  // bytes per Vt row (296 bf16)
+#define AT_LDS_BYTES (AT_KEYS * 128 + 64 * AT_VT_STRIDE)
+
+__global__ __launch_bounds__(256) void clip_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
+                                                        int C, float scale) {
+  __shared__ __attribute__((aligned(16))) char lds[AT_LDS_BYTES];
+  char* Ks = lds;
+  char* Vt = lds + AT_KEYS * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int h = blockIdx.x;
+  const size_t f = blockIdx.y;
+  const size_t ld = (size_t)3 * C;
+  const bf16_t* base = qkv + f * S * ld + (size_t)h * 64;
+
+  // ---- stage K (swizzled rows) and V (transposed) -------------------------
+  for (int id = tid; id < AT_KEYS * 8; id += 256) {
+    const int row = id >> 3, c = id & 7;
+    uint4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (row < S) {
+      kv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + C + c * 8);
+      vv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + 2 * C + c * 8);
+    }
+    *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kv;
+    const int kpos = ((((row >> 2) ^ c) << 2) | (row & 3)) * 2;  // byte offset of this key inside a Vt row for d>>3 == c
+    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint16_t val = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffff));
+      *reinterpret_cast<uint16_t*>(Vt + (c * 8 + e) * AT_VT_STRIDE + kpos) = val;
+    }
+  }
+  __syncthreads();
+
+  const int nqt = (S + 15) >> 4;
+  // Vt fragment offsets: d = dt*16 + l15, (d>>3)&7 = 2*dt + (l15>>3)
+  int voff[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int d = dt * 16 + l15, cd = (d >> 3) & 7;
+    voff[dt][0] = d * AT_VT_STRIDE + ((q4 ^ cd) << 3);
+    voff[dt][1] = d * AT_VT_STRIDE + (((q4 + 4) ^ cd) << 3);
+  }
+  const int koff = l15 * 128;
+  const int ksw = l15 & 7;
+
+  for (int qt = wid; qt < nqt; qt += 4) {
+    // the K / Vt fragments are loop-invariant; keep the compiler from hoisting ~150 registers of
+    // LDS reads out of this loop (it costs the second wave per SIMD)
+    asm volatile("" ::: "memory");
+    int qrow = qt * 16 + l15;
+    const bool qvalid = qrow < S;
+    qrow = qvalid ? qrow : S - 1;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 32 + q4 * 8);
+
+    f32x4 sc[18];
+#pragma unroll
+    for (int kt = 0; kt < 18; ++kt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + koff + (((kk * 4 + q4) ^ ksw) << 4));
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], a, 0, 0, 0);
+      }
+      sc[kt] = a;
+    }
+    // softmax over keys: lane holds keys kt*16 + q4*4 + r for query l15
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 18; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + q4 * 4 + r;
+        const float s = key < S ? sc[kt][r] : -INFINITY;
+        sc[kt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 18; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf((sc[kt][r] - mx) * scale);
+        sc[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      union { bf16x8 v; uint32_t u[4]; } pf;
+      pf.u[0] = pack_bf16x2(sc[2 * c][0], sc[2 * c][1]);
+      pf.u[1] = pack_bf16x2(sc[2 * c][2], sc[2 * c][3]);
+      pf.u[2] = pack_bf16x2(sc[2 * c + 1][0], sc[2 * c + 1][1]);
+      pf.u[3] = pack_bf16x2(sc[2 * c + 1][2], sc[2 * c + 1][3]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        union { bf16x8 v; uint2 h[2]; } vf;
+        vf.h[0] = *reinterpret_cast<const uint2*>(Vt + voff[dt][0] + c * 64);
+        vf.h[1] = *reinterpret_cast<const uint2*>(Vt + voff[dt][1] + c * 64);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
+      }
+    }
+    if (qvalid) {
+      bf16_t* orow = out + (f * S + qrow) * (size_t)C + (size_t)h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+        pk.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+        *reinterpret_cast<uint2*>(orow + dt * 16 + q4 * 4) = pk;
+      }
+    }
+  }
+}
+
+// ===========================================================================
+struct ClipWs {
+  bf16_t *x, *h, *qkv, *a, *u, *patches, *pooled;
+  size_t bytes;
+};
+
+ClipWs clip_carve(void* ws, const tspo_clip_config& c, int n) {
+  tspo::Carver cv(ws);
+  ClipWs w;
+  const int gw = c.image / c.patch, P = gw * gw, S = P + 1;
+  const size_t M = (size_t)n * S;
+  const int Kp = (int)tspo::align_up((size_t)3 * c.patch * c.patch, 64);
+  w.x = cv.take<bf16_t>(M * c.hidden);
+  w.h = cv.take<bf16_t>(M * c.hidden);
+  w.qkv = cv.take<bf16_t>(M * 3 * c.hidden);
+  w.a = cv.take<bf16_t>(M * c.hidden);
+  w.u = cv.take<bf16_t>(M * c.mlp);
+  w.patches = cv.take<bf16_t>((size_t)n * P * Kp);
+  w.pooled = cv.take<bf16_t>((size_t)n * c.hidden);
+  w.bytes = cv.bytes();
+  return w;
+}
+
+int clip_check_cfg(const tspo_clip_config& c) {
+  TSPO_REQUIRE(c.hidden >= 64 && c.hidden % 64 == 0 && c.hidden <= 4096, "clip: hidden=%d must be a multiple of 64 <= 4096", c.hidden);
+  TSPO_REQUIRE(c.heads >= 1 && c.hidden == c.heads * 64, "clip: head_dim must be 64 (hidden=%d heads=%d)", c.hidden, c.heads);
+  TSPO_REQUIRE(c.mlp >= 64 && c.mlp % 64 == 0, "clip: mlp=%d must be a multiple of 64", c.mlp);
+  TSPO_REQUIRE(c.proj >= 8 && c.proj % 8 == 0, "clip: proj=%d must be a multiple of 8", c.proj);
+  TSPO_REQUIRE(c.patch >= 1 && c.image >= c.patch && c.image % c.patch == 0, "clip: image=%d patch=%d", c.image, c.patch);
+  const int gw = c.image / c.patch;
+  TSPO_REQUIRE(gw * gw + 1 <= AT_KEYS, "clip: %d tokens exceed the %d-token attention kernel", gw * gw + 1, AT_KEYS);
+  TSPO_REQUIRE(c.layers >= 0, "clip: layers=%d", c.layers);
+  return TSPO_OK;
+}
+
+int run_ln(const bf16_t* in, bf16_t* out, const float* g, const float* b, long rows, int C, long is, long os, float eps,
+           hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, in, out, g, b, rows, C, is, os,
+                     eps);
+  return tspo::check_launch("layernorm");
+}
+
+}  // namespace
+
+extern "C" size_t tspo_clip_workspace_bytes(const tspo_clip_config* cfg, int n_frames) {
+  if (!cfg || n_frames < 1 || cfg->patch < 1 || cfg->image < cfg->patch) return 0;
+  return clip_carve(nullptr, *cfg, n_frames).bytes;
+}
+
+extern "C" int tspo_gemm_bf16(const void* A, const void* W, const float* bias, const void* residual, void* C,
+                              int out_dtype, int M, int N, int K, int act, tspo_stream_t stream) {
+  TSPO_REQUIRE(A && W && C, "gemm_bf16: null pointer");
+  TSPO_REQUIRE(M >= 1 && N >= 8 && N % 8 == 0 && K >= 64 && K % 64 == 0, "gemm_bf16: bad dims M=%d N=%d K=%d", M, N, K);
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.R = (const bf16_t*)residual; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.P = 1;
+  int epi;
+  if (out_dtype == TSPO_F32) {
+    TSPO_REQUIRE(!bias && !residual && act == 0, "gemm_bf16: f32 output supports no epilogue");
+    epi = GE_F32;
+  } else {
+    TSPO_REQUIRE(out_dtype == TSPO_BF16, "gemm_bf16: out_dtype must be TSPO_BF16 or TSPO_F32");
+    TSPO_REQUIRE(bias, "gemm_bf16: bf16 output needs a bias vector");
+    TSPO_REQUIRE(!(residual && act), "gemm_bf16: residual and activation are exclusive");
+    epi = residual ? GE_RESID : (act == 1 ? GE_GELU : GE_BIAS);
+  }
+  return gemm_dispatch(epi, g, (hipStream_t)stream);
+}
+
+extern "C" int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
+                                     float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream) {
+  TSPO_REQUIRE(w && pixels && feat && workspace, "clip_vit_forward: null pointer");
+  TSPO_REQUIRE(n_frames >= 1, "clip_vit_forward: n_frames=%d", n_frames);
+  const tspo_clip_config& c = w->cfg;
+  if (int e = clip_check_cfg(c)) return e;
+  TSPO_REQUIRE(w->patch_w && w->pos_emb && w->pre_g && w->pre_b && w->post_g && w->post_b && w->proj_w &&
+                   (c.layers == 0 || w->layers),
+               "clip_vit_forward: null weight pointer");
+  ClipWs b = clip_carve(workspace, c, n_frames);
+  if (workspace_bytes < b.bytes)
+    return tspo::set_err(TSPO_EWORKSPACE, "clip_vit_forward: workspace %zu < %zu", workspace_bytes, b.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int gw = c.image / c.patch, P = gw * gw, S = P + 1, C = c.hidden;
+  const int Kp = (int)tspo::align_up((size_t)3 * c.patch * c.patch, 64);
+  const long M = (long)n_frames * S;
+  TSPO_REQUIRE(M * (long)c.mlp < (1L << 40) && M < (1L << 31), "clip_vit_forward: n_frames too large");
+
+  // 1. patch gather (+ normalise) and CLS rows
+  {
+    const size_t total = (size_t)n_frames * P * (Kp / 8);
+    unsigned nb = (unsigned)((total + 255) / 256);
+    if (nb > 65536u) nb = 65536u;
+    switch (pixel_dtype) {
+      case TSPO_F32: hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
+      case TSPO_BF16: hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
+      case TSPO_F16: hipLaunchKernelGGL(patch_gather_kernel<_Float16>, dim3(nb), dim3(256), 0, st, (const _Float16*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
+      case TSPO_U8: hipLaunchKernelGGL(patch_gather_kernel<uint8_t>, dim3(nb), dim3(256), 0, st, (const uint8_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
+      default: return tspo::set_err(TSPO_EINVAL, "clip_vit_forward: bad pixel_dtype %d", pixel_dtype);
+    }
+    unsigned cb = (unsigned)(((size_t)n_frames * C + 255) / 256);
+    if (cb > 4096u) cb = 4096u;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(cb), dim3(256), 0, st, w->pos_emb, b.x, n_frames, S, C);
+  }
+  // 2. patch embedding GEMM (+ position embedding, rows remapped past each frame's CLS row)
+  {
+    GemmArgs g{};
+    g.A = b.patches; g.W = (const bf16_t*)w->patch_w; g.C = b.x; g.pos = w->pos_emb;
+    g.M = n_frames * P; g.N = C; g.K = Kp; g.P = P;
+    if (int e = launch_gemm<GE_PATCH>(g, st)) return e;
+  }
+  // 3. pre-LN (in place)
+  if (int e = run_ln(b.x, b.x, w->pre_g, w->pre_b, M, C, C, C, c.ln_eps, st)) return e;
+  // 4. transformer blocks
+  for (int l = 0; l < c.layers; ++l) {
+    const tspo_clip_layer& L = w->layers[l];
+    TSPO_REQUIRE(L.ln1_g && L.ln1_b && L.wqkv && L.bqkv && L.wo && L.bo && L.ln2_g && L.ln2_b && L.w1 && L.b1 && L.w2 && L.b2,
+                 "clip_vit_forward: null pointer in layer %d", l);
+    if (int e = run_ln(b.x, b.h, L.ln1_g, L.ln1_b, M, C, C, C, c.ln_eps, st)) return e;
+    GemmArgs g{};
+    g.A = b.h; g.W = (const bf16_t*)L.wqkv; g.bias = L.bqkv; g.C = b.qkv; g.M = (int)M; g.N = 3 * C; g.K = C; g.P = 1;
+    if (int e = launch_gemm<GE_BIAS>(g, st)) return e;
+    hipLaunchKernelGGL(clip_attn_kernel, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
+    if (int e = tspo::check_launch("clip_attn")) return e;
+    g = GemmArgs{};
+    g.A = b.a; g.W = (const bf16_t*)L.wo; g.bias = L.bo; g.R = b.x; g.C = b.x; g.M = (int)M; g.N = C; g.K = C; g.P = 1;
+    if (int e = launch_gemm<GE_RESID>(g, st)) return e;
+    if (int e = run_ln(b.x, b.h, L.ln2_g, L.ln2_b, M, C, C, C, c.ln_eps, st)) return e;
+    g = GemmArgs{};
+    g.A = b.h; g.W = (const bf16_t*)L.w1; g.bias = L.b1; g.C = b.u; g.M = (int)M; g.N = c.mlp; g.K = C; g.P = 1;
+    if (int e = launch_gemm<GE_GELU>(g, st)) return e;
+    g = GemmArgs{};
+    g.A = b.u; g.W = (const bf16_t*)L.w2; g.bias = L.b2; g.R = b.x; g.C = b.x; g.M = (int)M; g.N = C; g.K = c.mlp; g.P = 1;
+    if (int e = launch_gemm<GE_RESID>(g, st)) return e;
+  }
+  // 5. CLS pool + post-LN + projection
+  if (int e = run_ln(b.x, b.pooled, w->post_g, w->post_b, n_frames, C, (long)S * C, C, c.ln_eps, st)) return e;
+  {
+    GemmArgs g{};
+    g.A = b.pooled; g.W = (const bf16_t*)w->proj_w; g.C = feat; g.M = n_frames; g.N = c.proj; g.K = C; g.P = 1;
+    if (int e = launch_gemm<GE_F32>(g, st)) return e;
+  }
+  return TSPO_OK;
+}

@@ -1,0 +1,322 @@
+"""Tensor-level wrappers over the C ABI (include/tspo_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every
+computation below is a hand-written HIP kernel in libtspo_hip.so.  All
+functions require CUDA(ROCm) tensors and raise otherwise - there is no CPU
+path in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TSPO_BF16, TSPO_F16, TSPO_F32, TSPO_U8, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.TspoHipError("tspo_amd ops need GPU tensors (no CPU fallback); got a tensor on " + str(t.device))
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------------------
+# samplers
+# ---------------------------------------------------------------------------
+
+def topk_sorted(scores: torch.Tensor, k: int) -> torch.Tensor:
+    """scores [T] or [B,T] -> ascending int64 indices [min(T,k)] / [B,min(T,k)]."""
+    _need_gpu(scores)
+    squeeze = scores.ndim == 1
+    s = _f32c(scores.view(1, -1) if squeeze else scores)
+    B, T = s.shape
+    ke = min(T, int(k))
+    if ke < 1:
+        raise ValueError("topk_sorted: k must be >= 1")
+    idx = torch.empty((B, ke), dtype=torch.int64, device=s.device)
+    check(_lib.lib().tspo_topk_sorted(_ptr(s), B, T, int(k), _ptr(idx), _stream()), "tspo_topk_sorted")
+    return idx[0] if squeeze else idx
+
+
+def binmax(scores: torch.Tensor, k: int) -> torch.Tensor:
+    _need_gpu(scores)
+    squeeze = scores.ndim == 1
+    s = _f32c(scores.view(1, -1) if squeeze else scores)
+    B, T = s.shape
+    ke = min(T, int(k))
+    if ke < 1:
+        raise ValueError("binmax: k must be >= 1")
+    idx = torch.empty((B, ke), dtype=torch.int64, device=s.device)
+    check(_lib.lib().tspo_binmax(_ptr(s), B, T, int(k), _ptr(idx), _stream()), "tspo_binmax")
+    return idx[0] if squeeze else idx
+
+
+def gumbel_topk(logits: torch.Tensor, k: int, G: int = 1, noise: Optional[torch.Tensor] = None, seed: int = 0,
+                offset: int = 0, tau: float = 1.0, want_probs: bool = False, want_noise: bool = False):
+    """logits [B,T]; noise [B,G,T] or None (in-kernel Philox).  Returns dict with idx [B,G,k], logp [B,T]
+    and optionally probs / noise [B,G,T]."""
+    _need_gpu(logits, noise)
+    l = _f32c(logits)
+    B, T = l.shape
+    if k > T:
+        raise RuntimeError(f"selected index k out of range (k={k} > T={T})")  # torch.topk's error class
+    n = None
+    if noise is not None:
+        n = _f32c(noise)
+        if tuple(n.shape) != (B, G, T):
+            raise ValueError(f"noise must be [B,G,T]={B, G, T}, got {tuple(n.shape)}")
+    dev = l.device
+    idx = torch.empty((B, G, k), dtype=torch.int64, device=dev)
+    logp = torch.empty((B, T), dtype=torch.float32, device=dev)
+    probs = torch.empty((B, G, T), dtype=torch.float32, device=dev) if want_probs else None
+    nout = torch.empty((B, G, T), dtype=torch.float32, device=dev) if want_noise else None
+    check(_lib.lib().tspo_gumbel_topk(_ptr(l), _ptr(n), seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), B, G, T, int(k),
+                                      float(tau), _ptr(idx), _ptr(logp), _ptr(probs), _ptr(nout), _stream()),
+          "tspo_gumbel_topk")
+    return {"idx": idx, "logp": logp, "probs": probs, "noise": nout}
+
+
+def grpo_advantage(rewards: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
+    """rewards [B,G] -> advantages [B,G]."""
+    _need_gpu(rewards)
+    r = _f32c(rewards)
+    B, G = r.shape
+    adv = torch.empty_like(r)
+    check(_lib.lib().tspo_grpo_advantage(_ptr(r), B, G, float(eps), _ptr(adv), _stream()), "tspo_grpo_advantage")
+    return adv
+
+
+def pg_grad_logits(logp: torch.Tensor, idx: torch.Tensor, adv: torch.Tensor, scale: float = 1.0):
+    """logp [B,T], idx [B,G,k] int64 ascending, adv [B,G] -> (dlogits [B,T], loss [B])."""
+    _need_gpu(logp, idx, adv)
+    lp, a = _f32c(logp), _f32c(adv)
+    ix = idx.to(torch.int64).contiguous()
+    B, T = lp.shape
+    _, G, k = ix.shape
+    dl = torch.empty_like(lp)
+    loss = torch.empty((B,), dtype=torch.float32, device=lp.device)
+    check(_lib.lib().tspo_pg_grad_logits(_ptr(lp), _ptr(ix), _ptr(a), B, G, T, k, float(scale), _ptr(dl), _ptr(loss),
+                                         _stream()), "tspo_pg_grad_logits")
+    return dl, loss
+
+
+# ---------------------------------------------------------------------------
+# selector (flat parameter bucket; reference key names are views into it)
+# ---------------------------------------------------------------------------
+# order inside the flat bucket; q|k|v weights are contiguous so the fused [3D,D] projection needs no copy
+FLAT_LAYOUT = (
+    ("temporal.Self_q.weight", "w"), ("temporal.Self_k.weight", "w"), ("temporal.Self_v.weight", "w"),
+    ("temporal.Self_q.bias", "b"), ("temporal.Self_k.bias", "b"), ("temporal.Self_v.bias", "b"),
+    ("mlp.0.weight", "w"), ("mlp.0.bias", "b"), ("mlp.2.weight", "w"), ("mlp.2.bias", "b"),
+    ("temporal.ffn_o.weight", "w"), ("temporal.ffn_o.bias", "b"),   # present, never used (temporal_agent.py:77-79)
+)
+
+
+def flat_offsets(D: int) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
+    off, out = 0, {}
+    for name, kind in FLAT_LAYOUT:
+        shape = (D, D) if kind == "w" else (D,)
+        out[name] = (off, shape)
+        off += D * D if kind == "w" else D
+    out["__total__"] = (off, ())
+    return out
+
+
+def trainable_numel(D: int) -> int:
+    """elements of the bucket that receive gradients (everything except ffn_o)."""
+    return flat_offsets(D)["temporal.ffn_o.weight"][0]
+
+
+def _sel_structs(flat: torch.Tensor, D: int, cls):
+    o = flat_offsets(D)
+    base = flat.data_ptr()
+    s = cls()
+    s.wqkv = base + 4 * o["temporal.Self_q.weight"][0]
+    s.bqkv = base + 4 * o["temporal.Self_q.bias"][0]
+    s.w1 = base + 4 * o["mlp.0.weight"][0]
+    s.b1 = base + 4 * o["mlp.0.bias"][0]
+    s.w2 = base + 4 * o["mlp.2.weight"][0]
+    s.b2 = base + 4 * o["mlp.2.bias"][0]
+    return s
+
+
+def selector_workspace(B, T, D, H, M, window, device) -> torch.Tensor:
+    n = _lib.lib().tspo_selector_workspace_bytes(B, T, D, H, M, window)
+    if n == 0:
+        raise ValueError("selector: bad dims")
+    return torch.empty((n,), dtype=torch.uint8, device=device)
+
+
+def selector_forward(flat: torch.Tensor, img: torch.Tensor, txt: torch.Tensor, clip: Optional[torch.Tensor],
+                     H: int, window: int, tau: float, want_attn: bool = True, ws: Optional[torch.Tensor] = None):
+    """flat: f32 parameter bucket (FLAT_LAYOUT). img [B,T,D], txt [B,M,D], clip [B,T] ->
+    (scores [B,T] f32, temporal_attn [B,T,D] f32 | None, workspace)."""
+    _need_gpu(flat, img, txt, clip)
+    assert flat.dtype == torch.float32 and flat.is_contiguous()
+    x, e = _f32c(img), _f32c(txt)
+    B, T, D = x.shape
+    M = e.shape[1]
+    c = _f32c(clip) if clip is not None else None
+    if ws is None:
+        ws = selector_workspace(B, T, D, H, M, window, x.device)
+    scores = torch.empty((B, T), dtype=torch.float32, device=x.device)
+    attn = torch.empty((B, T, D), dtype=torch.float32, device=x.device) if want_attn else None
+    w = _sel_structs(flat, D, _lib.SelectorWeights)
+    check(_lib.lib().tspo_selector_forward(C.byref(w), _ptr(x), _ptr(e), _ptr(c), B, T, D, H, M, int(window), float(tau),
+                                           _ptr(scores), _ptr(attn), _ptr(ws), ws.numel(), _stream()),
+          "tspo_selector_forward")
+    return scores, attn, ws
+
+
+def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dscores, H, window, tau, ws):
+    """Writes the gradient of every trainable tensor into `flat_grad` (same layout as `flat`)."""
+    _need_gpu(flat, flat_grad, img, txt, dscores, ws)
+    x, e, d = _f32c(img), _f32c(txt), _f32c(dscores)
+    B, T, D = x.shape
+    M = e.shape[1]
+    w = _sel_structs(flat, D, _lib.SelectorWeights)
+    g = _sel_structs(flat_grad, D, _lib.SelectorGrads)
+    check(_lib.lib().tspo_selector_backward(C.byref(w), _ptr(x), _ptr(e), _ptr(d), B, T, D, H, M, int(window), float(tau),
+                                            C.byref(g), _ptr(ws), ws.numel(), _stream()), "tspo_selector_backward")
+
+
+def grad_norm_scale(grad: torch.Tensor, n: int, pre_scale: float = 1.0, max_norm: float = 1.0) -> torch.Tensor:
+    """-> device tensor [2] = (||g||, clip coefficient * pre_scale); no host sync."""
+    _need_gpu(grad)
+    out = torch.empty((2,), dtype=torch.float32, device=grad.device)
+    ws = torch.empty((2048,), dtype=torch.uint8, device=grad.device)
+    check(_lib.lib().tspo_grad_norm_scale(_ptr(grad), n, float(pre_scale), float(max_norm), _ptr(out), _ptr(ws),
+                                          ws.numel(), _stream()), "tspo_grad_norm_scale")
+    return out
+
+
+def adamw_step(param, grad, m, v, n: int, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+               grad_scale: float = 1.0, d_grad_scale: Optional[torch.Tensor] = None):
+    _need_gpu(param, grad, m, v, d_grad_scale)
+    check(_lib.lib().tspo_adamw_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, float(lr), float(beta1), float(beta2),
+                                     float(eps), float(weight_decay), int(step), float(grad_scale), _ptr(d_grad_scale),
+                                     _stream()), "tspo_adamw_step")
+
+
+# ---------------------------------------------------------------------------
+# CLIP ViT frame encoder
+# ---------------------------------------------------------------------------
+_PIX_DTYPES = {torch.float32: TSPO_F32, torch.bfloat16: TSPO_BF16, torch.float16: TSPO_F16, torch.uint8: TSPO_U8}
+
+
+class ClipVitWeights:
+    """Device-resident, kernel-ready copy of a HF CLIP vision tower + visual_projection
+    (bf16 [out,in] matrices, fp32 vectors, q|k|v fused, class_embedding folded into pos row 0,
+    conv weight flattened and K-padded to a multiple of 64)."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], cfg: dict, device):
+        self.cfg = dict(cfg)
+        dev = torch.device(device)
+        self._keep = []
+
+        def f32(t):
+            t = torch.as_tensor(t).detach().to(device=dev, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        def b16(t):
+            t = torch.as_tensor(t).detach().to(device=dev, dtype=torch.float32).to(torch.bfloat16).contiguous()
+            self._keep.append(t)
+            return t
+
+        p = "vision_model."
+        C_, patch = cfg["hidden"], cfg["patch"]
+        kreal = 3 * patch * patch
+        kp = (kreal + 63) // 64 * 64
+        pw = torch.as_tensor(state[p + "embeddings.patch_embedding.weight"]).float().reshape(C_, kreal)
+        pw = torch.nn.functional.pad(pw, (0, kp - kreal))
+        pos = torch.as_tensor(state[p + "embeddings.position_embedding.weight"]).float().clone()
+        pos[0] += torch.as_tensor(state[p + "embeddings.class_embedding"]).float()
+        self.layers = (_lib.ClipLayer * max(1, cfg["layers"]))()
+        for l in range(cfg["layers"]):
+            q = f"{p}encoder.layers.{l}."
+            L = self.layers[l]
+            wqkv = torch.cat([torch.as_tensor(state[q + f"self_attn.{n}_proj.weight"]).float() for n in "qkv"], 0)
+            bqkv = torch.cat([torch.as_tensor(state[q + f"self_attn.{n}_proj.bias"]).float() for n in "qkv"], 0)
+            L.ln1_g = f32(state[q + "layer_norm1.weight"]).data_ptr(); L.ln1_b = f32(state[q + "layer_norm1.bias"]).data_ptr()
+            L.wqkv = b16(wqkv).data_ptr(); L.bqkv = f32(bqkv).data_ptr()
+            L.wo = b16(state[q + "self_attn.out_proj.weight"]).data_ptr(); L.bo = f32(state[q + "self_attn.out_proj.bias"]).data_ptr()
+            L.ln2_g = f32(state[q + "layer_norm2.weight"]).data_ptr(); L.ln2_b = f32(state[q + "layer_norm2.bias"]).data_ptr()
+            L.w1 = b16(state[q + "mlp.fc1.weight"]).data_ptr(); L.b1 = f32(state[q + "mlp.fc1.bias"]).data_ptr()
+            L.w2 = b16(state[q + "mlp.fc2.weight"]).data_ptr(); L.b2 = f32(state[q + "mlp.fc2.bias"]).data_ptr()
+        w = _lib.ClipWeights()
+        w.cfg = _lib.ClipConfig(cfg["hidden"], cfg["layers"], cfg["heads"], cfg["mlp"], cfg["patch"], cfg["image"],
+                                cfg["proj"], float(cfg.get("ln_eps", 1e-5)))
+        w.patch_w = b16(pw).data_ptr()
+        w.pos_emb = f32(pos).data_ptr()
+        w.pre_g = f32(state[p + "pre_layrnorm.weight"]).data_ptr(); w.pre_b = f32(state[p + "pre_layrnorm.bias"]).data_ptr()
+        w.post_g = f32(state[p + "post_layernorm.weight"]).data_ptr(); w.post_b = f32(state[p + "post_layernorm.bias"]).data_ptr()
+        w.proj_w = b16(state["visual_projection.weight"]).data_ptr()
+        w.layers = C.cast(self.layers, C.POINTER(_lib.ClipLayer))
+        self.struct = w
+        self.device = dev
+        self._ws = None
+
+    def workspace(self, n_frames: int) -> torch.Tensor:
+        n = _lib.lib().tspo_clip_workspace_bytes(C.byref(self.struct.cfg), n_frames)
+        if n == 0:
+            raise ValueError("clip: bad config")
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+
+def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pixels [N,3,H,W] (f32/bf16/f16 normalised, or uint8 raw) -> features f32 [N, proj]."""
+    _need_gpu(pixels)
+    if pixels.dtype not in _PIX_DTYPES:
+        raise TypeError(f"unsupported pixel dtype {pixels.dtype}")
+    px = pixels.contiguous()
+    N = px.shape[0]
+    cfg = w.cfg
+    if tuple(px.shape[1:]) != (3, cfg["image"], cfg["image"]):
+        raise ValueError(f"pixels must be [N,3,{cfg['image']},{cfg['image']}], got {tuple(px.shape)}")
+    ws = w.workspace(N)
+    feat = out if out is not None else torch.empty((N, cfg["proj"]), dtype=torch.float32, device=px.device)
+    check(_lib.lib().tspo_clip_vit_forward(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
+                                           ws.numel(), _stream()), "tspo_clip_vit_forward")
+    return feat
+
+
+def clip_scores(txt: torch.Tensor, feat: torch.Tensor) -> torch.Tensor:
+    """txt [B,M,D] (row 0 used), feat [B,T,D] -> cosine [B,T]."""
+    _need_gpu(txt, feat)
+    e, f = _f32c(txt), _f32c(feat)
+    B, T, D = f.shape
+    out = torch.empty((B, T), dtype=torch.float32, device=f.device)
+    check(_lib.lib().tspo_clip_scores(_ptr(e), _ptr(f), B, T, D, e.shape[1], _ptr(out), _stream()), "tspo_clip_scores")
+    return out
+
+
+def gemm_bf16(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, act: int = 0, out_f32: bool = False):
+    """C = A @ W^T (+bias)(+residual | quick_gelu): the encoder's MFMA GEMM, exposed for tests / microbenchmarks."""
+    _need_gpu(A, W, bias, residual)
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
+    A, W = A.contiguous(), W.contiguous()
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=A.device)
+    b = _f32c(bias) if bias is not None else None
+    r = residual.contiguous() if residual is not None else None
+    check(_lib.lib().tspo_gemm_bf16(_ptr(A), _ptr(W), _ptr(b), _ptr(r), _ptr(out), TSPO_F32 if out_f32 else TSPO_BF16,
+                                    M, N, K, int(act), _stream()), "tspo_gemm_bf16")
+    return out
