@@ -65,6 +65,15 @@ def test_topk_ties_and_batch(golden):
     np.testing.assert_array_equal(ops.topk_sorted(G_(x), 5).cpu().numpy(), O.topk_sorted(T_(x), 5).numpy())
 
 
+def _check_logp(got, ref):
+    """log(softmax(x)) as the reference computes it (softmax THEN log, model/utils.py:78): exact in the
+    normal range; where the probability is an fp32 denormal (< 1.2e-38, logp < -87.3) the CPU keeps
+    denormals and may round to 0 one element earlier/later than the GPU, so only 'very negative' is checked."""
+    normal = ref > -87.0
+    np.testing.assert_allclose(got[normal], ref[normal], rtol=1e-5, atol=2e-5)
+    assert np.all(got[~normal] < -86.0)
+
+
 @pytest.mark.parametrize("case", GUMBEL_CASES, ids=[c[0] for c in GUMBEL_CASES])
 def test_gumbel_topk_injected_noise(golden, case):
     name, T, k, G, scale = case
@@ -72,7 +81,7 @@ def test_gumbel_topk_injected_noise(golden, case):
     logits = gumbel_logits(T, scale)
     out = ops.gumbel_topk(G_(logits[None]), k, G, noise=G_(g[f"{name}.noise"][None]), want_probs=True)
     np.testing.assert_array_equal(out["idx"][0].cpu().numpy(), g[f"{name}.idx"])          # bit-exact
-    np.testing.assert_allclose(out["logp"][0].cpu().numpy(), g[f"{name}.logp"], rtol=1e-5, atol=2e-5)
+    _check_logp(out["logp"][0].cpu().numpy(), g[f"{name}.logp"])
     np.testing.assert_allclose(out["probs"][0].cpu().numpy(), g[f"{name}.probs"], rtol=0, atol=2e-6)
 
 
@@ -87,7 +96,7 @@ def test_gumbel_topk_philox_and_batch():
         for g in range(G):
             idx, _, lp = O.gumbel_topk(T_(logits[b]), T_(noise[b, g]), k)
             np.testing.assert_array_equal(out["idx"][b, g].cpu().numpy(), idx.numpy())
-        np.testing.assert_allclose(out["logp"][b].cpu().numpy(), lp.numpy(), rtol=1e-5, atol=2e-5)
+        _check_logp(out["logp"][b].cpu().numpy(), lp.numpy())
     # different offset -> different stream; same (seed, offset) -> identical
     o2 = ops.gumbel_topk(G_(logits), k, G, seed=2024, offset=7)
     o3 = ops.gumbel_topk(G_(logits), k, G, seed=2024, offset=8)
@@ -172,6 +181,13 @@ def test_selector_backward_adamw_golden(golden, case):
         if "ffn_o" in pn:
             assert np.all(got == 0)
             continue
+        if pn == "temporal.Self_k.bias":
+            # d/d(b_k) is identically zero (a shift common to all keys of a softmax row): the reference's
+            # autograd value is pure round-off; ours must be round-off on the scale of the q-bias gradient
+            qb = g[f"{name}.grad.temporal.Self_q.bias"] if f"{name}.grad.temporal.Self_q.bias" in g.files \
+                else g[f"{name}.gradsl.temporal.Self_q.bias"]
+            assert np.abs(got).max() <= 1e-4 * np.abs(qb).max()
+            continue
         if f"{name}.grad.{pn}" in g.files:
             ref = g[f"{name}.grad.{pn}"].flatten()
             np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
@@ -191,8 +207,35 @@ def test_selector_backward_adamw_golden(golden, case):
     for pn in O.SELECTOR_KEYS:
         if "ffn_o" in pn:
             continue
+        if pn == "temporal.Self_k.bias":
+            continue      # Adam turns the round-off-only gradient into +-lr steps (in the reference too): not comparable
         off, shape = offs[pn]
-        np.testing.assert_allclose(flat[off:off + 256].cpu().numpy(), g[f"{name}.after.{pn}"], rtol=1e-4, atol=2e-6)
+        ref = g[f"{name}.after.{pn}"]
+        # first Adam step = lr * g/(|g| + eps'): ill-conditioned where |g| ~ eps = 1e-8 (dead-ReLU rows etc. carry
+        # round-off-only gradients in the reference too), so only elements with a well-defined gradient are compared
+        gref = (g[f"{name}.grad.{pn}"].flatten() if f"{name}.grad.{pn}" in g.files else g[f"{name}.gradsl.{pn}"])[:ref.size]
+        ok = np.abs(gref) > 1e-4 * np.abs(gref).max()
+        assert ok.sum() >= 16
+        np.testing.assert_allclose(flat[off:off + ref.size].cpu().numpy()[ok], ref[ok], rtol=1e-4, atol=2e-6)
+
+
+def test_adamw_matches_oracle_on_identical_inputs():
+    n = 100003
+    p0, g0 = synth.normal((n,), 61, 0.05), synth.normal((n,), 62, 1e-3)
+    p, m, v = G_(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    po, mo, vo = T_(p0).clone(), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        gs = synth.normal((n,), 62 + step, 1e-3)
+        ns = ops.grad_norm_scale(G_(gs), n, 0.5, 1.0)
+        tn = float(np.linalg.norm(gs.astype(np.float64)))
+        assert abs(ns[0].item() - tn) < 1e-5 * tn
+        scale = O.clip_grad_scale(tn, 1.0) * 0.5
+        assert abs(ns[1].item() - scale) < 1e-6
+        ops.adamw_step(p, G_(gs), m, v, n, lr=5e-4, step=step, weight_decay=0.01, d_grad_scale=ns)
+        po, mo, vo = O.adamw_step(po, T_(gs), mo, vo, step, 5e-4, wd=0.01, grad_scale=ns[1].item())
+        np.testing.assert_allclose(p.cpu().numpy(), po.numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(m.cpu().numpy(), mo.numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(v.cpu().numpy(), vo.numpy(), rtol=1e-5, atol=1e-12)
 
 
 def test_selector_backward_batched_sums():
