@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py - frames scored/s (+ rollouts/s) of the TSPO temporal-sampling hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): TSPO-0.4B frame selection, T=1024 synthetic frames per video,
+top-k=32: pixels [B,T,3,224,224] resident in HBM -> CLIP-L/14 encode (bf16 MFMA) -> cosine clip score ->
+temporal scoring head (fp32, window 12, tau 0.025) -> greedy top-k.  One "step" = one such pass over one
+batch of B videos per GPU.  value = B*T*N*K / max-over-ranks wall time (weak scaling: videos are
+independent, no data-path collective).  Also timed: the policy side of one TSPO training step
+(configs[2]: B=4, T=512, G=8, k=16; reward LLM excluded, rewards synthetic) -> "rollouts_per_s".
+Weights are random-init tensors of the CLIP-L/14 + selector shapes (no network for checkpoints).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIP_L14 = dict(hidden=1024, layers=24, heads=16, mlp=4096, patch=14, image=224, proj=768)
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md (2.5 PF dense; 5 PF figure is 2:1 sparse)
+
+
+def gemm_flops_per_frame(c):
+    S = (c["image"] // c["patch"]) ** 2 + 1
+    P = S - 1
+    C, mlp = c["hidden"], c["mlp"]
+    patch = 2 * P * (3 * c["patch"] ** 2) * C
+    layer = 2 * S * C * 3 * C + 2 * S * C * C + 2 * 2 * S * C * mlp
+    return patch + c["layers"] * layer + 2 * C * c["proj"]
+
+
+def attn_flops_per_frame(c):
+    S = (c["image"] // c["patch"]) ** 2 + 1
+    return c["layers"] * 2 * 2 * S * S * c["hidden"]
+
+
+def random_clip_state(c, device, seed=11, dtype=torch.float32):
+    """Random-init CLIP-L/14 vision tower (HF key names), generated on `device`."""
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def rn(*shape, std=0.02, mean=0.0):
+        return torch.randn(*shape, generator=g, device=device, dtype=dtype) * std + mean
+
+    C, mlp, p = c["hidden"], c["mlp"], "vision_model."
+    S = (c["image"] // c["patch"]) ** 2 + 1
+    st = {p + "embeddings.class_embedding": rn(C), p + "embeddings.patch_embedding.weight": rn(C, 3, c["patch"], c["patch"]),
+          p + "embeddings.position_embedding.weight": rn(S, C), p + "pre_layrnorm.weight": rn(C, std=0.05, mean=1.0),
+          p + "pre_layrnorm.bias": rn(C), p + "post_layernorm.weight": rn(C, std=0.05, mean=1.0),
+          p + "post_layernorm.bias": rn(C), "visual_projection.weight": rn(c["proj"], C)}
+    for l in range(c["layers"]):
+        q = f"{p}encoder.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            st[q + f"self_attn.{nm}.weight"] = rn(C, C)
+            st[q + f"self_attn.{nm}.bias"] = rn(C)
+        for nm in ("layer_norm1", "layer_norm2"):
+            st[q + nm + ".weight"] = rn(C, std=0.05, mean=1.0)
+            st[q + nm + ".bias"] = rn(C)
+        st[q + "mlp.fc1.weight"], st[q + "mlp.fc1.bias"] = rn(mlp, C), rn(mlp)
+        st[q + "mlp.fc2.weight"], st[q + "mlp.fc2.bias"] = rn(C, mlp), rn(C)
+    return st
+
+
+def random_selector_state(D, device, seed=7):
+    g = torch.Generator(device=device).manual_seed(seed)
+    names = ["temporal.Self_q", "temporal.Self_k", "temporal.Self_v", "temporal.ffn_o", "mlp.0", "mlp.2"]
+    st = {}
+    for n in names:   # HF _init_weights: N(0, 0.02) weights, zero bias (tspo_trainer.py:201)
+        st[n + ".weight"] = torch.randn(D, D, generator=g, device=device) * 0.02
+        st[n + ".bias"] = torch.zeros(D, device=device)
+    return st
+
+
+def flat_from_state(st, D, device):
+    from tspo_amd import ops
+    offs = ops.flat_offsets(D)
+    flat = torch.zeros(offs["__total__"][0], dtype=torch.float32, device=device)
+    for name, (off, shape) in offs.items():
+        if not name.startswith("__"):
+            flat[off:off + st[name].numel()] = st[name].flatten().to(device)
+    return flat
+
+
+def cpu_baseline(T, k, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path, oracle/tspo_oracle.py) on the host cores, bounded sample:
+    CLIP-L on n frames (frames are independent -> per-frame cost), selector + top-k at the full T."""
+    from oracle import tspo_oracle as O
+    c = CLIP_L14
+    w = random_clip_state(c, "cpu")
+    sel = random_selector_state(768, "cpu")
+    g = torch.Generator().manual_seed(1234)
+    cores = torch.get_num_threads()
+
+    def enc(n):
+        px = torch.randn(n, 3, c["image"], c["image"], generator=g)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.clip_vit_forward(w, px, num_heads=c["heads"], patch=c["patch"])
+        return time.perf_counter() - t0
+
+    enc(2)                                     # warm-up (thread pool, allocator)
+    t8 = enc(8)
+    n = int(max(8, min(256, (budget_s - 3.0) / (t8 / 8) // 8 * 8)))
+    tn = enc(n)
+    feats = torch.randn(T, 768, generator=g)
+    txt = torch.randn(1, 768, generator=g)
+    with torch.no_grad():
+        clip = O.clip_cosine_scores(txt, feats)
+        O.selector_forward(sel, feats, txt, clip, 12, 0.025)
+        t0 = time.perf_counter()
+        s, _ = O.selector_forward(sel, feats, txt, clip, 12, 0.025)
+        O.topk_sorted(s, k)
+        tsel = time.perf_counter() - t0
+    per_frame = tn / n + tsel / T
+    return {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32): CLIP-L/14 on {n} frames in {tn:.2f}s + selector/top-k at T={T} in "
+                      f"{tsel * 1e3:.1f}ms, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1024, help="T, frames per video")
+    ap.add_argument("--videos", type=int, default=1, help="B, videos per GPU per step")
+    ap.add_argument("--topk", type=int, default=32)
+    ap.add_argument("--pixels", default="u8", choices=["u8", "bf16", "f16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollouts", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU path in the product); use gpurun")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # RCCL
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from tspo_amd import ops
+    from tspo_amd.pipeline import FrameScorer, PolicyTrainer
+
+    c = CLIP_L14
+    B, T, k = a.videos, a.frames, a.topk
+    clipw = ops.ClipVitWeights(random_clip_state(c, dev), c, dev)
+    flat = flat_from_state(random_selector_state(768, dev), 768, dev)
+    scorer = FrameScorer(clipw, flat)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    if a.pixels == "u8":
+        pixels = torch.randint(0, 256, (B, T, 3, c["image"], c["image"]), generator=g, device=dev, dtype=torch.uint8)
+    else:
+        dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.pixels]
+        pixels = torch.randn(B, T, 3, c["image"], c["image"], generator=g, device=dev).to(dt)
+    txt = torch.randn(B, 1, 768, generator=torch.Generator(device=dev).manual_seed(4321), device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt_ = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt_, op=dist.ReduceOp.MAX)
+        return dt_.item()
+
+    # ---- frames scored / s ---------------------------------------------------
+    out = {}
+
+    def score_step():
+        out["idx"], out["scores"], _ = scorer(pixels, txt, k)
+
+    sec = timed(score_step, a.steps, a.warmup)
+    frames = B * T * world * a.steps
+    fps = frames / sec
+    assert out["idx"].shape == (B, min(T, k)) and bool((out["idx"][:, 1:] > out["idx"][:, :-1]).all())
+
+    # ---- rollouts / s (policy side of one TSPO step, configs[2]) --------------
+    rollouts = None
+    if not a.no_rollouts:
+        Bt, Tt, G, kt, tau = 4, 512, 8, 16, 0.025
+        gen = torch.Generator(device=dev).manual_seed(99 + rank)
+        feats = torch.randn(Bt, Tt, 768, generator=gen, device=dev)
+        ttxt = torch.randn(Bt, 1, 768, generator=gen, device=dev)
+        clip = ops.clip_scores(ttxt, feats)
+        rew = (torch.rand(Bt, G, generator=gen, device=dev) > 0.5).float() + torch.rand(Bt, G, generator=gen, device=dev)
+        trainer = PolicyTrainer(flat.clone())
+        rsec = timed(lambda: trainer.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 20), 3)
+        rollouts = Bt * G * world * max(a.steps, 20) / rsec
+
+    # ---- roofline of the dominant kernel (bf16 MFMA GEMM), live HIP-event timing --------------------------
+    roof = None
+    if rank == 0 and not a.no_profile:
+        px = pixels.reshape(B * T, *pixels.shape[2:])
+        ops.clip_vit_profile(clipw, px)
+        pr = ops.clip_vit_profile(clipw, px)
+        gflop = gemm_flops_per_frame(c) * B * T
+        ach = gflop / (pr["gemm_ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "gemm_bf16_kernel",
+                "launches_per_step": pr["gemm_launches"],
+                "avg_launch_ms": round(pr["gemm_ms"] / pr["gemm_launches"], 4),
+                "alg_flop_per_launch_avg": gflop / pr["gemm_launches"],
+                "breakdown_ms": {kk: round(v, 3) for kk, v in pr.items() if kk.endswith("_ms")},
+                "attn_achieved_tflops": round(attn_flops_per_frame(c) * B * T / (pr["attn_ms"] * 1e-3) / 1e12, 1)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(T, k)
+
+    if rank == 0:
+        line = {
+            "metric": "frames_scored_per_s", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: TSPO-0.4B frame selection (CLIP-L/14 encode + scoring head + top-k)",
+                       "frames_per_video": T, "videos_per_gpu_per_step": B, "topk": k, "window": 12, "tau": 0.025,
+                       "pixels": a.pixels, "weights": "random-init CLIP-L/14 + selector", "parallelism": f"dp{world}"},
+            "rollouts_per_s": None if rollouts is None else round(rollouts, 1),
+            "rollouts_config": None if rollouts is None else {"workload": "configs[2] policy step (reward LLM excluded)",
+                                                              "B": 4, "T": 512, "G": 8, "k": 16},
+            "encode_tflops": round((gemm_flops_per_frame(c) + attn_flops_per_frame(c)) * fps / 1e12, 1),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,6 +214,14 @@ size_t tspo_clip_workspace_bytes(const tspo_clip_config* cfg, int n_frames);
 int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
                           float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream);
 
+/* Same computation, with a hipEvent recorded on `stream` after every kernel launch; synchronises on the
+ * last event (profiling entry point - the only one that waits) and returns in HOST array host_ms6:
+ * [0] GEMM ms, [1] attention ms, [2] LayerNorm ms, [3] patch gather ms, [4] total ms, [5] number of GEMM
+ * launches.  bench.py derives roofline.achieved for the GEMM kernel from [0].                              */
+int tspo_clip_vit_profile(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
+                          float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
+                          float* host_ms6);
+
 /* torch.nn.CosineSimilarity(dim=-1)(text[b,0,:], feat[b,t,:])  (temporal_agent.py:167).
  * txt f32 [B,M,D] (row 0 of each prompt is used), feat f32 [B,T,D] -> clip f32 [B,T]. */
 int tspo_clip_scores(const float* txt, const float* feat, int B, int T, int D, int M, float* clip,

@@ -472,6 +472,39 @@ int clip_check_cfg(const tspo_clip_config& c) {
   return TSPO_OK;
 }
 
+// Optional per-kernel-class timing with HIP events on the launch stream (bench / profiling only).
+enum { PK_GEMM = 0, PK_ATTN = 1, PK_LN = 2, PK_GATHER = 3, PK_NKIND = 4 };
+struct Prof {
+  hipStream_t st;
+  hipEvent_t ev[512];
+  int kind[512];
+  int n = 0;
+  bool on = false;
+  void start(hipStream_t s) { st = s; on = true; n = 0; tick(-1); }
+  void tick(int k) {
+    if (!on || n >= 512) return;
+    (void)hipEventCreate(&ev[n]);
+    (void)hipEventRecord(ev[n], st);
+    kind[n] = k;
+    ++n;
+  }
+  void finish(float* ms /* PK_NKIND + 2 */) {
+    for (int i = 0; i < PK_NKIND + 2; ++i) ms[i] = 0.f;
+    if (!on || n == 0) return;
+    (void)hipEventSynchronize(ev[n - 1]);
+    int ngemm = 0;
+    for (int i = 1; i < n; ++i) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, ev[i - 1], ev[i]);
+      ms[kind[i]] += t;
+      ms[PK_NKIND] += t;
+      ngemm += kind[i] == PK_GEMM;
+    }
+    ms[PK_NKIND + 1] = (float)ngemm;
+    for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]);
+  }
+};
+
 int run_ln(const bf16_t* in, bf16_t* out, const float* g, const float* b, long rows, int C, long is, long os, float eps,
            hipStream_t st) {
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, in, out, g, b, rows, C, is, os,
@@ -506,8 +539,8 @@ extern "C" int tspo_gemm_bf16(const void* A, const void* W, const float* bias, c
   return gemm_dispatch(epi, g, (hipStream_t)stream);
 }
 
-extern "C" int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
-                                     float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream) {
+static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames, float* feat,
+                             void* workspace, size_t workspace_bytes, tspo_stream_t stream, Prof& prof) {
   TSPO_REQUIRE(w && pixels && feat && workspace, "clip_vit_forward: null pointer");
   TSPO_REQUIRE(n_frames >= 1, "clip_vit_forward: n_frames=%d", n_frames);
   const tspo_clip_config& c = w->cfg;
@@ -539,6 +572,7 @@ extern "C" int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pix
     unsigned cb = (unsigned)(((size_t)n_frames * C + 255) / 256);
     if (cb > 4096u) cb = 4096u;
     hipLaunchKernelGGL(cls_rows_kernel, dim3(cb), dim3(256), 0, st, w->pos_emb, b.x, n_frames, S, C);
+    prof.tick(PK_GATHER);
   }
   // 2. patch embedding GEMM (+ position embedding, rows remapped past each frame's CLS row)
   {
@@ -546,37 +580,66 @@ extern "C" int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pix
     g.A = b.patches; g.W = (const bf16_t*)w->patch_w; g.C = b.x; g.pos = w->pos_emb;
     g.M = n_frames * P; g.N = C; g.K = Kp; g.P = P;
     if (int e = launch_gemm<GE_PATCH>(g, st)) return e;
+    prof.tick(PK_GEMM);
   }
   // 3. pre-LN (in place)
   if (int e = run_ln(b.x, b.x, w->pre_g, w->pre_b, M, C, C, C, c.ln_eps, st)) return e;
+  prof.tick(PK_LN);
   // 4. transformer blocks
   for (int l = 0; l < c.layers; ++l) {
     const tspo_clip_layer& L = w->layers[l];
     TSPO_REQUIRE(L.ln1_g && L.ln1_b && L.wqkv && L.bqkv && L.wo && L.bo && L.ln2_g && L.ln2_b && L.w1 && L.b1 && L.w2 && L.b2,
                  "clip_vit_forward: null pointer in layer %d", l);
     if (int e = run_ln(b.x, b.h, L.ln1_g, L.ln1_b, M, C, C, C, c.ln_eps, st)) return e;
+    prof.tick(PK_LN);
     GemmArgs g{};
     g.A = b.h; g.W = (const bf16_t*)L.wqkv; g.bias = L.bqkv; g.C = b.qkv; g.M = (int)M; g.N = 3 * C; g.K = C; g.P = 1;
     if (int e = launch_gemm<GE_BIAS>(g, st)) return e;
+    prof.tick(PK_GEMM);
     hipLaunchKernelGGL(clip_attn_kernel, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     if (int e = tspo::check_launch("clip_attn")) return e;
+    prof.tick(PK_ATTN);
     g = GemmArgs{};
     g.A = b.a; g.W = (const bf16_t*)L.wo; g.bias = L.bo; g.R = b.x; g.C = b.x; g.M = (int)M; g.N = C; g.K = C; g.P = 1;
     if (int e = launch_gemm<GE_RESID>(g, st)) return e;
+    prof.tick(PK_GEMM);
     if (int e = run_ln(b.x, b.h, L.ln2_g, L.ln2_b, M, C, C, C, c.ln_eps, st)) return e;
+    prof.tick(PK_LN);
     g = GemmArgs{};
     g.A = b.h; g.W = (const bf16_t*)L.w1; g.bias = L.b1; g.C = b.u; g.M = (int)M; g.N = c.mlp; g.K = C; g.P = 1;
     if (int e = launch_gemm<GE_GELU>(g, st)) return e;
+    prof.tick(PK_GEMM);
     g = GemmArgs{};
     g.A = b.u; g.W = (const bf16_t*)L.w2; g.bias = L.b2; g.R = b.x; g.C = b.x; g.M = (int)M; g.N = C; g.K = c.mlp; g.P = 1;
     if (int e = launch_gemm<GE_RESID>(g, st)) return e;
+    prof.tick(PK_GEMM);
   }
   // 5. CLS pool + post-LN + projection
   if (int e = run_ln(b.x, b.pooled, w->post_g, w->post_b, n_frames, C, (long)S * C, C, c.ln_eps, st)) return e;
+  prof.tick(PK_LN);
   {
     GemmArgs g{};
     g.A = b.pooled; g.W = (const bf16_t*)w->proj_w; g.C = feat; g.M = n_frames; g.N = c.proj; g.K = C; g.P = 1;
     if (int e = launch_gemm<GE_F32>(g, st)) return e;
+    prof.tick(PK_GEMM);
   }
   return TSPO_OK;
+}
+
+extern "C" int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
+                                     float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream) {
+  Prof prof;
+  return clip_forward_impl(w, pixels, pixel_dtype, n_frames, feat, workspace, workspace_bytes, stream, prof);
+}
+
+extern "C" int tspo_clip_vit_profile(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
+                                     float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
+                                     float* host_ms6) {
+  TSPO_REQUIRE(host_ms6, "clip_vit_profile: null host_ms6");
+  static thread_local Prof prof;  // 512 events: keep it off the stack
+  prof.start((hipStream_t)stream);
+  const int rc = clip_forward_impl(w, pixels, pixel_dtype, n_frames, feat, workspace, workspace_bytes, stream, prof);
+  prof.finish(host_ms6);
+  prof.on = false;
+  return rc;
 }

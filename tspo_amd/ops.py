@@ -297,6 +297,20 @@ def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torc
     return feat
 
 
+def clip_vit_profile(w: ClipVitWeights, pixels: torch.Tensor) -> Dict[str, float]:
+    """One encode with a hipEvent after every launch -> ms per kernel class (profiling; synchronises)."""
+    _need_gpu(pixels)
+    px = pixels.contiguous()
+    N = px.shape[0]
+    ws = w.workspace(N)
+    feat = torch.empty((N, w.cfg["proj"]), dtype=torch.float32, device=px.device)
+    ms = (C.c_float * 6)()
+    check(_lib.lib().tspo_clip_vit_profile(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
+                                           ws.numel(), _stream(), ms), "tspo_clip_vit_profile")
+    return {"gemm_ms": ms[0], "attn_ms": ms[1], "ln_ms": ms[2], "gather_ms": ms[3], "total_ms": ms[4],
+            "gemm_launches": int(ms[5])}
+
+
 def clip_scores(txt: torch.Tensor, feat: torch.Tensor) -> torch.Tensor:
     """txt [B,M,D] (row 0 used), feat [B,T,D] -> cosine [B,T]."""
     _need_gpu(txt, feat)
