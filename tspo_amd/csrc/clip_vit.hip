@@ -32,7 +32,9 @@ enum { GE_BIAS = 0, GE_GELU = 1, GE_RESID = 2, GE_F32 = 3, GE_PATCH = 4 };
 struct GemmArgs {
   const bf16_t* A; const bf16_t* W; const float* bias; const bf16_t* R; void* C;
   const float* pos;  // GE_PATCH: pos_emb [S, N]
-  int M, N, K, tilesN, nwg, P;  // P: patches per frame (GE_PATCH row remap)
+  int M, N, K, tilesN, nwg, P;  // P: patches per frame (GE_PATCH row remap); P < 0 = ablation hooks (tests only)
+  int variant;                  // 0 = auto; 1 = 128x128 2-stage; 2 = persistent 256x128 ring; 6 = persistent 256x256
+  int ngrp;                     // 0 = auto N-group count per XCD
 };
 
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int rows_total, int row0, int K, int kt,
@@ -160,13 +162,390 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   }
 }
 
+
+// ===========================================================================
+// GEMM v2: persistent 256x128x64, 8 waves (4x2, 64x64 each), 3-stage LDS ring
+// (3 x 48 KB) filled by LDS-DMA that stays in flight across barriers (counted
+// s_waitcnt vmcnt + raw s_barrier), and a ring that runs CONTINUOUSLY across the
+// tiles a workgroup owns, so the next tile's first stages stream in under the
+// current tile's last MFMAs and its epilogue stores.  Measured motivation
+// (profiles/r1_a_*): with the 2-stage kernel above one K-step took ~3.3k cycles
+// for ~1.1k cycles of MFMA because each step waited for its own loads.
+// Tiles are dealt per XCD (blockIdx % 8 observed = XCD): the 32 workgroups of an
+// XCD walk the N tiles of consecutive M panels together, so an A panel is read
+// from HBM once per XCD and served from that XCD's L2 to the others.
+// ===========================================================================
+#define G2_BM 256
+#define G2_BN 128
+#define G2_STAGE (G2_BM * 128 + G2_BN * 128)  // 49152 B
+#define G2_NSTAGE 3
+
+__device__ __forceinline__ void g2_stage(const GemmArgs& g, int m0, int n0, int kt, char* buf, int wid, int lane) {
+  const int rin = lane >> 3, slot = lane & 7;
+  // A: 32 pieces of 8 rows; wave takes pieces wid*4..+3
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int piece = wid * 4 + p;
+    const int r = piece * 8 + rin;
+    int gr = m0 + r;
+    gr = gr < g.M ? gr : g.M - 1;
+    const bf16_t* src = g.A + (size_t)gr * g.K + (size_t)kt * GT_BK + ((slot ^ rin) << 3);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+  }
+  // W: 16 pieces; wave takes pieces wid*2, wid*2+1
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int piece = wid * 2 + p;
+    const int r = piece * 8 + rin;
+    int gr = n0 + r;
+    gr = gr < g.N ? gr : g.N - 1;
+    const bf16_t* src = g.W + (size_t)gr * g.K + (size_t)kt * GT_BK + ((slot ^ rin) << 3);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(buf + G2_BM * 128 + piece * 1024), 16, 0, 0);
+  }
+}
+
 template <int EPI>
-int launch_gemm(GemmArgs g, hipStream_t st) {
+__global__ __launch_bounds__(512) void gemm_bf16_p3_kernel(GemmArgs g, int tilesM, int ngrp) {
+  // the ONLY LDS object: 3 stages + the whole bias vector (<= 4096 floats).  Keeping the bias in LDS matters:
+  // an ordinary global load in the epilogue makes hipcc drain vmcnt(0), i.e. the LDS-DMA ring, at its first use.
+  __shared__ __attribute__((aligned(16))) char lds[G2_NSTAGE * G2_STAGE + 16384];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  float* lbias = reinterpret_cast<float*>(lds + G2_NSTAGE * G2_STAGE);
+  if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID)
+    for (int i = tid; i < g.N; i += 512) lbias[i] = g.bias[i];
+  const int nk = g.K / GT_BK;
+  // Tile ownership per XCD (blockIdx % 8, observed placement - speed only).  The N tiles are split into `ngrp`
+  // groups so that one XCD only ever touches W rows worth <= ~2.5 MB (its 4 MB L2 keeps them resident instead of
+  // cycling the whole W through LRU), and the M panels are dealt round-robin over the 8/ngrp XCDs of a group.
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
+  const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
+  const int panels = (tilesM - pset + npset - 1) / npset;
+  const int ntile_x = panels * n_per;
+  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
+  const int total_it = my_tiles * nk;
+  if (total_it == 0) return;
+
+  // issue-side cursor (runs 2 stages ahead of the compute cursor)
+  int i_it = 0, i_kt = 0, i_s = wl;
+  int i_m0 = ((i_s / n_per) * npset + pset) * G2_BM, i_n0 = (grp * n_per + i_s % n_per) * G2_BN;
+  int i_rot = g.P < 0 ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
+  auto issue_next = [&]() {
+    // K-rotation: the workgroups that share an A panel (different N tiles, same XCD) start their K loops at
+    // different offsets, so each 64-wide K slice of the panel is pulled from HBM by ONE of them while the others
+    // find it in the XCD's L2 instead of all of them stalling on the same miss together.
+    int kt_eff = i_kt + i_rot;
+    kt_eff = kt_eff >= nk ? kt_eff - nk : kt_eff;
+    g2_stage(g, i_m0, i_n0, kt_eff, lds + (i_it % G2_NSTAGE) * G2_STAGE, wid, lane);
+    ++i_it;
+    if (++i_kt == nk) {
+      i_kt = 0;
+      i_s += nwl;
+      i_m0 = ((i_s / n_per) * npset + pset) * G2_BM;
+      i_n0 = (grp * n_per + i_s % n_per) * G2_BN;
+      i_rot = g.P < 0 ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
+    }
+  };
+  issue_next();
+  if (total_it > 1) issue_next();
+
+  int offA[4], offW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    offA[i] = (wm * 64 + i * 16 + l15) * 128;
+    offW[i] = G2_BM * 128 + (wn * 64 + i * 16 + l15) * 128;
+  }
+  const int sw = l15 & 7;
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int c_kt = 0, c_s = wl, stage = 0;
+  bool drained = false;  // true right after an epilogue: its stores share the VM counter with the loads
+  for (int it = 0; it < total_it; ++it) {
+    // stage `it` must have landed for every wave; stage it+1 (6 LDS-DMA ops per wave) may stay in flight
+    if (it + 1 < total_it && !drained) {
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    drained = false;
+    if (i_it < total_it && g.P != -2) issue_next();  // refills the buffer whose reads finished before the barrier above
+    const char* cur = lds + stage * G2_STAGE;
+    if (g.P != -3)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int co = (((kk * 4 + q4) ^ sw) << 4);
+      bf16x8 fa[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *reinterpret_cast<const bf16x8*>(cur + offA[i] + co);
+        fw[i] = *reinterpret_cast<const bf16x8*>(cur + offW[i] + co);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+    stage = stage == G2_NSTAGE - 1 ? 0 : stage + 1;
+    if (++c_kt == nk) {
+      // ---- epilogue of tile c_s (the ring keeps streaming the next tile meanwhile) ----
+      const int m0 = ((c_s / n_per) * npset + pset) * G2_BM, n0 = (grp * n_per + c_s % n_per) * G2_BN;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + l15;
+        size_t orow = (size_t)m;
+        int prow = 0;
+        if (EPI == GE_PATCH) {
+          const int f = m / g.P;
+          prow = 1 + (m - f * g.P);
+          orow = (size_t)f * (g.P + 1) + prow;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n = n0 + wn * 64 + ni * 16 + q4 * 4;
+          f32x4 v = acc[ni][mi];
+          acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (m >= g.M || n >= g.N) continue;
+          if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) v += *reinterpret_cast<const f32x4*>(lbias + n);
+          if (EPI == GE_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+          }
+          if (EPI == GE_PATCH) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
+          const size_t o = orow * g.N + n;
+          if (EPI == GE_RESID) {
+            const uint2 rv = *reinterpret_cast<const uint2*>(g.R + o);
+            v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+            v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+          }
+          if (EPI == GE_F32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
+          } else {
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + o) = pk;
+          }
+        }
+      }
+      c_kt = 0;
+      c_s += nwl;
+      drained = true;
+    }
+  }
+}
+
+template <int EPI>
+int launch_gemm_p3(GemmArgs g, hipStream_t st) {
+  const int tilesM = (g.M + G2_BM - 1) / G2_BM;
+  g.tilesN = (g.N + G2_BN - 1) / G2_BN;
+  g.nwg = tilesM * g.tilesN;
+  int grid = 256;  // one persistent workgroup per CU (160 KB of LDS each)
+  int ngrp = 1;
+  const double wbytes = (double)g.N * g.K * 2.0;
+  while (ngrp < 8 && wbytes / ngrp > 2.5e6 && g.tilesN % (ngrp * 2) == 0) ngrp *= 2;
+  if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
+  hipLaunchKernelGGL((gemm_bf16_p3_kernel<EPI>), dim3(grid), dim3(512), 0, st, g, tilesM, ngrp);
+  return tspo::check_launch("gemm_bf16_p3");
+}
+
+template <int EPI>
+int launch_gemm_v1(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + GT_BM - 1) / GT_BM;
   g.tilesN = (g.N + GT_BN - 1) / GT_BN;
   g.nwg = tilesM * g.tilesN;
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(g.nwg), dim3(256), 0, st, g);
   return tspo::check_launch("gemm_bf16");
+}
+
+
+// ===========================================================================
+// GEMM v3: persistent 256x256x64, 8 waves (2x4, 128x64 each = 8x4 MFMA tiles, 128 fp32 accumulators per lane),
+// 2-stage LDS ring (2 x 64 KB) + bias (16 KB) = 144 KB.  Why: measured on the 256x128 kernel, the LDS-DMA stream
+// alone tops out at ~12.6 TB/s chip-wide (~26 B/clk/CU) whatever the L2 hit rate, i.e. ~1.07 PFLOP/s at the
+// 85 FLOP/B of a 256x128 tile; a 256x256 tile needs 128 FLOP/B (ceiling ~1.6 PFLOP/s) and reads 25 % fewer LDS
+// bytes per MFMA.  Same continuous ring across the tiles a workgroup owns, same XCD/N-group ownership, same K-rotation.
+// ===========================================================================
+#define G3_BM 256
+#define G3_BN 256
+#define G3_STAGE (G3_BM * 128 + G3_BN * 128)  // 65536 B
+
+__device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int kt, char* buf, int wid, int lane) {
+  const int rin = lane >> 3, slot = lane & 7;
+  const size_t koff = (size_t)kt * GT_BK + ((slot ^ rin) << 3);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {  // A: 32 pieces of 8 rows
+    const int piece = wid * 4 + p;
+    int gr = m0 + piece * 8 + rin;
+    gr = gr < g.M ? gr : g.M - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
+                                     (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+  }
+  if (g.P == -4) return;  // test hook: A half only
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {  // W: 32 pieces of 8 rows
+    const int piece = wid * 4 + p;
+    int gr = n0 + piece * 8 + rin;
+    gr = gr < g.N ? gr : g.N - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.W + (size_t)gr * g.K + koff),
+                                     (__attribute__((address_space(3))) void*)(buf + G3_BM * 128 + piece * 1024), 16, 0, 0);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int tilesM, int ngrp) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE + 16384];  // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int wm = wid >> 2, wn = wid & 3;
+  float* lbias = reinterpret_cast<float*>(lds + 2 * G3_STAGE);
+  if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID)
+    for (int i = tid; i < g.N; i += 512) lbias[i] = g.bias[i];
+  const int nk = g.K / GT_BK;
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
+  const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
+  const int panels = (tilesM - pset + npset - 1) / npset;
+  const int ntile_x = panels * n_per;
+  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
+  const int total_it = my_tiles * nk;
+  if (total_it == 0) return;
+
+  int i_it = 0, i_kt = 0, i_s = wl;
+  int i_m0 = ((i_s / n_per) * npset + pset) * G3_BM, i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
+  int i_rot = (int)(((long)(i_s % n_per) * nk) / n_per);
+  auto issue_next = [&]() {
+    int kt_eff = i_kt + i_rot;
+    kt_eff = kt_eff >= nk ? kt_eff - nk : kt_eff;
+    g3_stage(g, i_m0, i_n0, kt_eff, lds + (i_it & 1) * G3_STAGE, wid, lane);
+    ++i_it;
+    if (++i_kt == nk) {
+      i_kt = 0;
+      i_s += nwl;
+      i_m0 = ((i_s / n_per) * npset + pset) * G3_BM;
+      i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
+      i_rot = (int)(((long)(i_s % n_per) * nk) / n_per);
+    }
+  };
+  issue_next();
+
+  int offA[8], offW[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) offA[i] = (wm * 128 + i * 16 + l15) * 128;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) offW[i] = G3_BM * 128 + (wn * 64 + i * 16 + l15) * 128;
+  const int sw = l15 & 7;
+
+  f32x4 acc[4][8];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int c_kt = 0, c_s = wl;
+  for (int it = 0; it < total_it; ++it) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage `it` landed everywhere; buffer (it+1)&1 is free
+    if (i_it < total_it && g.P != -2) issue_next();
+    const char* cur = lds + (it & 1) * G3_STAGE;
+    if (g.P > -3)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int co = (((kk * 4 + q4) ^ sw) << 4);
+      bf16x8 fa[8], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(cur + offW[i] + co);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(cur + offA[i] + co);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if (++c_kt == nk) {
+      const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + wm * 128 + mi * 16 + l15;
+        size_t orow = (size_t)m;
+        int prow = 0;
+        if (EPI == GE_PATCH) {
+          const int f = m / g.P;
+          prow = 1 + (m - f * g.P);
+          orow = (size_t)f * (g.P + 1) + prow;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n = n0 + wn * 64 + ni * 16 + q4 * 4;
+          f32x4 v = acc[ni][mi];
+          acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (m >= g.M || n >= g.N) continue;
+          if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) v += *reinterpret_cast<const f32x4*>(lbias + n);
+          if (EPI == GE_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+          }
+          if (EPI == GE_PATCH) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
+          const size_t o = orow * g.N + n;
+          if (EPI == GE_RESID) {
+            const uint2 rv = *reinterpret_cast<const uint2*>(g.R + o);
+            v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+            v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+          }
+          if (EPI == GE_F32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
+          } else {
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + o) = pk;
+          }
+        }
+      }
+      c_kt = 0;
+      c_s += nwl;
+    }
+  }
+}
+
+template <int EPI>
+int launch_gemm_p256(GemmArgs g, hipStream_t st) {
+  const int tilesM = (g.M + G3_BM - 1) / G3_BM;
+  g.tilesN = (g.N + G3_BN - 1) / G3_BN;
+  g.nwg = tilesM * g.tilesN;
+  int ngrp = 1;
+  const double wbytes = (double)g.N * g.K * 2.0;
+  while (ngrp < 8 && wbytes / ngrp > 2.5e6 && g.tilesN % (ngrp * 2) == 0) ngrp *= 2;
+  hipLaunchKernelGGL((gemm_bf16_p256_kernel<EPI>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
+  return tspo::check_launch("gemm_bf16_p256");
+}
+
+// Variant choice: the persistent 256x256 kernel whenever there is at least one tile per CU; the small
+// 128x128 kernel otherwise.  Variants 2..29 are reachable only through tspo_gemm_bf16's test hook (act >> 8):
+// 2 = 256x128 ring, 3 = 2 without K-rotation, 4/5 = 2 compute-only / loads-only, 6 = 256x256, 7/8/9 = 6 compute-only /
+// loads-only / A-loads-only, 1x = 2 with x N-groups, 2x = 2 loads-only with x N-groups.
+template <int EPI>
+int launch_gemm(GemmArgs g, hipStream_t st) {
+  const bool big = (long)g.M * g.N >= (long)256 * 256 * 256 && g.K >= 128 && g.N <= 4096;
+  const int v = g.variant ? g.variant : (big ? 6 : 1);
+  if (v == 1) return launch_gemm_v1<EPI>(g, st);
+  if (v == 6) return launch_gemm_p256<EPI>(g, st);
+  if (v == 7) { g.P = -2; return launch_gemm_p256<EPI>(g, st); }
+  if (v == 8) { g.P = -3; return launch_gemm_p256<EPI>(g, st); }
+  if (v == 9) { g.P = -4; return launch_gemm_p256<EPI>(g, st); }
+  if (v >= 10 && v < 20) { g.ngrp = v - 10; return launch_gemm_p3<EPI>(g, st); }
+  if (v >= 20 && v < 30) { g.ngrp = v - 20; g.P = -3; return launch_gemm_p3<EPI>(g, st); }
+  if (v == 3) { g.P = -1; return launch_gemm_p3<EPI>(g, st); }
+  if (v == 4) { g.P = -2; return launch_gemm_p3<EPI>(g, st); }
+  if (v == 5) { g.P = -3; return launch_gemm_p3<EPI>(g, st); }
+  return launch_gemm_p3<EPI>(g, st);
 }
 
 int gemm_dispatch(int epi, const GemmArgs& g, hipStream_t st) {
@@ -526,6 +905,8 @@ extern "C" int tspo_gemm_bf16(const void* A, const void* W, const float* bias, c
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.R = (const bf16_t*)residual; g.C = C;
   g.M = M; g.N = N; g.K = K; g.P = 1;
+  const int variant = act >> 8;
+  act &= 0xff;
   int epi;
   if (out_dtype == TSPO_F32) {
     TSPO_REQUIRE(!bias && !residual && act == 0, "gemm_bf16: f32 output supports no epilogue");
@@ -536,6 +917,7 @@ extern "C" int tspo_gemm_bf16(const void* A, const void* W, const float* bias, c
     TSPO_REQUIRE(!(residual && act), "gemm_bf16: residual and activation are exclusive");
     epi = residual ? GE_RESID : (act == 1 ? GE_GELU : GE_BIAS);
   }
+  g.variant = variant;
   return gemm_dispatch(epi, g, (hipStream_t)stream);
 }
 
