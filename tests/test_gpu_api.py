@@ -1,0 +1,249 @@
+"""GPU tests of the drop-in Python surface (reference names / signatures) and of the fused pipelines,
+against the golden vectors generated from the reference and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from inputs import SELECTOR_CASES, GUMBEL_CASES, TRAIN_CASES, selector_inputs, gumbel_logits, train_inputs
+from oracle import tspo_oracle as O
+from tspo_amd import ops, synth
+from tspo_amd.pipeline import FrameScorer, PolicyTrainer
+from tspo_amd.policy import TemporalPolicy
+from tspo_amd.temporal_agent import MultiModal_Align, TSPOModel, inference_ts
+from tspo_amd.utils import gumbel_softmax
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T_(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def G_(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def make_selector(state, D, H, flatten=False, dtype=None):
+    m = MultiModal_Align(dim=D, num_heads=H)
+    m.load_state_dict({k: T_(v) for k, v in state.items()})
+    m.to(DEV)
+    if dtype is not None:
+        m.to(dtype)
+    if flatten:
+        m.flatten_parameters()
+    return m
+
+
+@pytest.mark.parametrize("case", SELECTOR_CASES[:5], ids=[c[0] for c in SELECTOR_CASES[:5]])
+@pytest.mark.parametrize("flatten", [False, True])
+def test_multimodal_align_module(golden, case, flatten):
+    name, T, D, H, w, tau, M, ks = case
+    g = golden["selector"]
+    img, txt, clip, state = selector_inputs(name, T, D, M)
+    m = make_selector(state, D, H, flatten)
+    with torch.no_grad():
+        s, h = m(G_(img), G_(txt), G_(clip), window_size=w, score_tau=tau)
+    assert s.shape == (T,) and h.shape == (1, T, D) and s.dtype == torch.float32
+    np.testing.assert_allclose(s.cpu().numpy(), g[f"{name}.scores"], rtol=2e-5, atol=2e-5 / tau)
+    np.testing.assert_allclose(h.cpu().numpy(), g[f"{name}.attn"], rtol=1e-4, atol=2e-5)
+    for k in ks:
+        sel, conf = inference_ts(s, "topk", k)
+        assert sel.dtype == torch.int64 and sel.device.type == "cuda" and conf is s
+        np.testing.assert_array_equal(sel.cpu().numpy(), g[f"{name}.topk{k}"])
+        np.testing.assert_array_equal(inference_ts(s, "bin-max", k)[0].cpu().numpy(), g[f"{name}.binmax{k}"])
+    if T >= 16:
+        assert inference_ts(s, "aks", 8)[0].cpu().tolist() == g[f"{name}.aks8"].tolist()
+
+
+def test_multimodal_align_bf16_like_reference(golden):
+    """The reference runs the selector in bf16 (gen_id_tspo.py:55): bf16 params/inputs are accepted, outputs keep
+    the input dtype; tolerance = bf16 rounding of inputs and weights (2^-8) amplified by 1/tau."""
+    name, T, D, H, w, tau, M, ks = SELECTOR_CASES[0]
+    img, txt, clip, state = selector_inputs(name, T, D, M)
+    m = make_selector(state, D, H, dtype=torch.bfloat16)
+    with torch.no_grad():
+        s, h = m(G_(img).bfloat16(), G_(txt).bfloat16(), G_(clip).bfloat16(), window_size=w, score_tau=tau)
+    assert s.dtype == torch.bfloat16 and h.dtype == torch.bfloat16
+    ref = golden["selector"][f"{name}.scores"]
+    assert np.abs(s.float().cpu().numpy() - ref).max() < 0.05 * np.abs(ref).max() + 0.5
+
+
+@pytest.mark.parametrize("case", GUMBEL_CASES[:2], ids=[c[0] for c in GUMBEL_CASES[:2]])
+def test_gumbel_softmax_api(golden, case):
+    name, T, k, G, scale = case
+    g = golden["gumbel"]
+    logits = G_(gumbel_logits(T, scale)).unsqueeze(1)
+    for i in range(G):
+        idx, probs, lp = gumbel_softmax(logits, sample_len=k, noise=G_(g[f"{name}.noise"][i]))
+        assert idx.shape == (k,) and probs.shape == (T,) and lp.shape == (T,)
+        np.testing.assert_array_equal(idx.cpu().numpy(), g[f"{name}.idx"][i])
+        np.testing.assert_allclose(probs.cpu().numpy(), g[f"{name}.probs"][i], atol=2e-6)
+    torch.manual_seed(5)
+    a = gumbel_softmax(logits, sample_len=k)[0]
+    torch.manual_seed(5)
+    b = gumbel_softmax(logits, sample_len=k)[0]
+    c = gumbel_softmax(logits, sample_len=k)[0]
+    assert torch.equal(a, b) and not torch.equal(a, c)            # torch.manual_seed controls the rollout
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=[c[0] for c in TRAIN_CASES])
+def test_reference_shaped_training_loop(golden, case):
+    """tspo_trainer.py:500-609 written exactly like the reference (G rollouts, G re-evaluations with grad,
+    advantage, exp(lp - sg(lp)) loss, loss.backward()) on the drop-in modules -> same indices, same grads."""
+    name, T, D, H, w, tau, k, G = case
+    g = golden["train"]
+    img, txt, clip, state, rewards = train_inputs(name, T, D, G)
+    pol = TemporalPolicy(D, H)
+    pol.multiModal_align.load_state_dict({n: T_(v) for n, v in state.items()})
+    pol.to(DEV)
+    pol.multiModal_align.flatten_parameters()
+    ie, te, cs = G_(img), G_(txt), G_(clip)
+    all_ts = []
+    with torch.no_grad():
+        for i in range(G):
+            ts_ids, _, _ = pol.temporal_sampling(ie, te, cs, sample_len=k, window_size=w, score_tau=tau,
+                                                 noise=G_(g[f"{name}.noise"][i]))
+            all_ts.append(ts_ids)
+    np.testing.assert_array_equal(torch.stack([t[1] for t in all_ts]).cpu().numpy(), g[f"{name}.idx"])
+    logps = []
+    for i in range(G):
+        _, lp, conf = pol.temporal_sampling(ie, te, cs, ts_ids=all_ts[i], sample_len=k, window_size=w, score_tau=tau)
+        logps.append(lp[all_ts[i][1]])
+    r = G_(rewards)
+    mean = r.view(-1, G).mean(dim=1).repeat_interleave(G, dim=0)
+    std = r.view(-1, G).std(dim=1).repeat_interleave(G, dim=0)
+    adv = (r - mean) / (std + 1e-4)
+    loss = 0.0
+    for i in range(G):
+        loss = loss + (-(torch.exp(logps[i] - logps[i].detach()).mean() * adv[i]))
+    loss = loss / G
+    for p in pol.parameters():
+        p.grad = None if p.grad is None else p.grad.zero_()
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{name}.loss"])) < 1e-5
+    for pn, p in pol.multiModal_align.named_parameters():
+        if "ffn_o" in pn:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0
+            continue
+        if pn == "temporal.Self_k.bias":
+            continue
+        got = p.grad.flatten().cpu().numpy()
+        if f"{name}.grad.{pn}" in g.files:
+            ref = g[f"{name}.grad.{pn}"].flatten()
+        else:
+            ref, got = g[f"{name}.gradsl.{pn}"], got[:256]
+        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=[c[0] for c in TRAIN_CASES])
+def test_fused_policy_step_equals_reference_loop(golden, case):
+    """PolicyTrainer.step (scores once, G rollouts in one launch, closed-form dL/ds, one backward, AdamW) ==
+    the reference's 2G-forward autograd loop + clip_grad_norm_ + AdamW."""
+    name, T, D, H, w, tau, k, G = case
+    g = golden["train"]
+    img, txt, clip, state, rewards = train_inputs(name, T, D, G)
+    m = make_selector(state, D, H, flatten=True)
+    tr = PolicyTrainer(m._flat, dim=D, heads=H, window_size=w, lr=5e-4)
+    st = tr.step(G_(img[None]), G_(txt[None]), G_(clip[None]), lambda idx: G_(rewards[None]), G, k, tau,
+                 noise=G_(g[f"{name}.noise"][None]))
+    np.testing.assert_array_equal(st["idx"][0].cpu().numpy(), g[f"{name}.idx"])
+    np.testing.assert_allclose(st["advantages"][0].cpu().numpy(), g[f"{name}.adv"], rtol=1e-5, atol=1e-6)
+    assert abs(st["loss"][0].item() - float(g[f"{name}.loss"])) < 1e-5
+    tn = float(g[f"{name}.gradnorm"])
+    assert abs(st["grad_norm_scale"][0].item() - tn) < 5e-4 * tn
+    offs = ops.flat_offsets(D)
+    for pn in O.SELECTOR_KEYS:
+        if "ffn_o" in pn or pn == "temporal.Self_k.bias":
+            continue
+        off, shape = offs[pn]
+        gref = (g[f"{name}.grad.{pn}"].flatten() if f"{name}.grad.{pn}" in g.files else g[f"{name}.gradsl.{pn}"])
+        n = min(256, gref.size)
+        np.testing.assert_allclose(tr.grad[off:off + n].cpu().numpy(), gref[:n], rtol=5e-4, atol=5e-5 * np.abs(gref).max())
+        ref = g[f"{name}.after.{pn}"]
+        ok = np.abs(gref[:ref.size]) > 1e-4 * np.abs(gref).max()
+        np.testing.assert_allclose(m._flat[off:off + ref.size].cpu().numpy()[ok], ref[ok], rtol=1e-4, atol=2e-6)
+    # the module's parameters ARE the bucket: the update is visible through the reference key names
+    assert torch.equal(dict(m.named_parameters())["mlp.2.bias"].data, m._flat[offs["mlp.2.bias"][0]:offs["mlp.2.bias"][0] + D])
+
+
+class _StubProcessor:
+    """CLIPProcessor stand-in (tokenizer files are not available offline): text -> fixed token ids,
+    images -> the real CLIPImageProcessor (resize-224 bicubic, centre crop, rescale, normalise)."""
+
+    def __init__(self):
+        from transformers import CLIPImageProcessor
+        self.ip = CLIPImageProcessor()
+
+    def __call__(self, text=None, images=None, return_tensors="pt", **kw):
+        from transformers import BatchEncoding, BatchFeature
+        if text is not None:
+            ids = torch.tensor([[49406, 320, 1125, 539, 320, 2368, 49407]])
+            return BatchEncoding({"input_ids": ids, "attention_mask": torch.ones_like(ids)})
+        return BatchFeature(self.ip(images=images, return_tensors="pt"))
+
+
+def test_tspo_model_end_to_end_small_config():
+    """TSPOModel.forward (reference entry point, temporal_agent.py:177-185) with a small random CLIP whose vision
+    tower has the ViT-L/14 geometry (257 tokens, head_dim 64): HIP features == transformers' own
+    get_image_features (fp32 CPU) within the bf16 tolerance; indices == oracle selection on the HIP scores."""
+    from transformers import CLIPConfig
+    cfg = CLIPConfig(text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                      vocab_size=49408, max_position_embeddings=77, projection_dim=768),
+                     vision_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                        image_size=224, patch_size=14, projection_dim=768), projection_dim=768)
+    torch.manual_seed(0)
+    model = TSPOModel(cfg).float().eval()
+    for p in model.vision_model.parameters():          # default init is tiny; make the tower non-trivial
+        if p.ndim >= 2:
+            torch.nn.init.normal_(p, std=0.05)
+    model.selector.load_state_dict({k: T_(v) for k, v in synth.selector_state(768, seed=2, std=0.02).items()})
+    frames = synth.uniform_u8((20, 240, 320, 3), 77)             # T=20 "llava"-style HWC uint8 frames
+    proc = _StubProcessor()
+    with torch.no_grad():
+        px = proc(images=[f for f in frames])["pixel_values"]
+        out = model.get_image_features(pixel_values=px)
+        ref_feat = out if isinstance(out, torch.Tensor) else out.pooler_output
+    model.to(DEV)
+    ts_ids, pred = model(proc, frames, "what is shown?", sample_num=6, window_size=12, method="topk")
+    feats, text, clip = model.extract_feature(proc, frames, "what is shown?")
+    err = (feats.float().cpu() - ref_feat).abs().max().item() / ref_feat.abs().max().item()
+    assert err < 3e-2, err
+    assert ts_ids.shape == (6,) and ts_ids.dtype == torch.int64 and bool((ts_ids[1:] > ts_ids[:-1]).all())
+    s_ref, _ = O.selector_forward({k: v.detach().cpu() for k, v in model.selector.state_dict().items()},
+                                  feats.float().cpu(), text.float().cpu(), clip.float().cpu(), 12, 0.025)
+    pred = pred.detach()
+    np.testing.assert_allclose(pred.float().cpu().numpy(), s_ref.numpy(), rtol=1e-4, atol=2e-3)
+    assert ts_ids.cpu().tolist() == O.topk_sorted(pred.float().cpu(), 6).tolist()
+    # qwen25vl-style CHW tensors take the other branch of extract_feature (temporal_agent.py:160-161)
+    chw = [torch.from_numpy(f).permute(2, 0, 1) for f in frames]
+    f2, _, _ = model.extract_feature(proc, chw, "what is shown?", processor_type="qwen25vl")
+    assert torch.equal(f2, feats)
+
+
+def test_full_size_properties_T1024():
+    """BASELINE configs[1] size (B=1, T=1024, CLIP-L/14, k=32) through size-independent properties: determinism,
+    frame independence (a permutation of the frames permutes the features), sorted distinct indices that are
+    exactly the top-k of the returned scores, and fp32 oracle agreement of the score stage on the GPU features."""
+    import bench
+    c = bench.CLIP_L14
+    clipw = ops.ClipVitWeights(bench.random_clip_state(c, DEV), c, DEV)
+    sel_state = bench.random_selector_state(768, DEV)
+    flat = bench.flat_from_state(sel_state, 768, DEV)
+    scorer = FrameScorer(clipw, flat)
+    gen = torch.Generator(device=DEV).manual_seed(1234)
+    px = torch.randint(0, 256, (1, 1024, 3, 224, 224), generator=gen, device=DEV, dtype=torch.uint8)
+    txt = torch.randn(1, 1, 768, generator=gen, device=DEV)
+    idx, scores, feats = scorer(px, txt, 32)
+    idx2, scores2, feats2 = scorer(px, txt, 32)
+    assert torch.equal(idx, idx2) and torch.equal(scores, scores2) and torch.equal(feats, feats2)
+    assert idx.shape == (1, 32) and bool((idx[0, 1:] > idx[0, :-1]).all())
+    assert idx[0].cpu().tolist() == O.topk_sorted(scores[0].cpu(), 32).tolist()
+    perm = torch.randperm(1024, generator=torch.Generator().manual_seed(3)).to(DEV)
+    fp = scorer.encode(px[:, perm])
+    assert torch.equal(fp[0], feats[0][perm])
+    assert torch.isfinite(feats).all() and feats.std() > 0
+    st = {k: v.cpu() for k, v in sel_state.items()}
+    clip_ref = O.clip_cosine_scores(txt[0].cpu(), feats[0].cpu())
+    s_ref, _ = O.selector_forward(st, feats[0].cpu(), txt[0].cpu(), clip_ref, 12, 0.025)
+    np.testing.assert_allclose(scores[0].cpu().numpy(), s_ref.numpy(), rtol=1e-4, atol=2e-3)

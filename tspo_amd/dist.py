@@ -1,0 +1,65 @@
+"""Data-parallel plumbing of the TSPO step over torch.distributed (backend "nccl" = RCCL over xGMI on
+MI355X; "gloo" in the CPU tests).  Replaces the DeepSpeed ZeRO-3 launcher of the reference
+(train_deepspeed.sh:14-16, scripts/zero3.json): only 2.95 M selector parameters train, so the whole
+exchange is ONE all-reduce of a 11.8 MB fp32 bucket per optimizer step plus ONE tiny packed metrics
+all-reduce (the reference issues 7 separate gathers, tspo_trainer.py:610-634)."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
+    """(rank, world, local_rank); initialises the default group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_prompts(n_global: int, world: int, rank: int) -> range:
+    """Contiguous shard of the global batch of prompts for `rank` (all G rollouts of a prompt stay on its
+    rank, so the group statistics of the advantage never cross ranks - tspo_trainer.py:587-592)."""
+    base, rem = divmod(n_global, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def allreduce_mean_(bucket: torch.Tensor, n: int, group=None) -> torch.Tensor:
+    """In-place mean over ranks of bucket[:n] (one collective)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(bucket[:n], op=dist.ReduceOp.SUM, group=group)
+        bucket[:n].div_(dist.get_world_size(group))
+    return bucket
+
+
+METRIC_KEYS = ("ts_length", "completion_length", "reward", "advantages", "reward_mean", "reward_std")
+
+
+def pack_metrics(values: Dict[str, float], rewards_per_func: Sequence[float]) -> torch.Tensor:
+    """One small vector for every metric the reference gathers (tspo_trainer.py:610-634)."""
+    return torch.tensor([float(values[k]) for k in METRIC_KEYS] + [float(x) for x in rewards_per_func] + [1.0],
+                        dtype=torch.float64)
+
+
+def reduce_metrics(packed: torch.Tensor, n_reward_funcs: int, reward_names: Sequence[str], group=None) -> Dict[str, float]:
+    """Mean over ranks with ONE all-reduce (last slot counts ranks)."""
+    t = packed.clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = t.device
+        if dist.get_backend(group) == "nccl" and not t.is_cuda:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t = t.to(dev)
+    t = t / t[-1]
+    out = {k: t[i].item() for i, k in enumerate(METRIC_KEYS)}
+    for j, name in enumerate(reward_names[:n_reward_funcs]):
+        out[f"rewards/{name}"] = t[len(METRIC_KEYS) + j].item()
+    return out
