@@ -378,12 +378,16 @@ int launch_gemm_v1(GemmArgs g, hipStream_t st) {
 #define G3_BN 256
 #define G3_STAGE (G3_BM * 128 + G3_BN * 128)  // 65536 B
 
-__device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int kt, char* buf, int wid, int lane) {
+// One stage = 64 LDS-DMA pieces of 1 KB.  Only the 4 waves of ONE wave-row (one per SIMD) issue them, the row
+// alternating every K-step: an LDS-DMA instruction costs its issuing wave ~60-180 cycles, so while a loader wave
+// is busy issuing, its SIMD partner (the other wave-row) has the matrix pipe to itself instead of both waves
+// queueing DMA issues and then both queueing MFMAs.
+__device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int kt, char* buf, int j, int lane) {
   const int rin = lane >> 3, slot = lane & 7;
   const size_t koff = (size_t)kt * GT_BK + ((slot ^ rin) << 3);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {  // A: 32 pieces of 8 rows
-    const int piece = wid * 4 + p;
+  for (int p = 0; p < 8; ++p) {  // A: 32 pieces of 8 rows, 8 per loader wave
+    const int piece = j * 8 + p;
     int gr = m0 + piece * 8 + rin;
     gr = gr < g.M ? gr : g.M - 1;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
@@ -391,8 +395,8 @@ __device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int 
   }
   if (g.P == -4) return;  // test hook: A half only
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {  // W: 32 pieces of 8 rows
-    const int piece = wid * 4 + p;
+  for (int p = 0; p < 8; ++p) {  // W: 32 pieces of 8 rows
+    const int piece = j * 8 + p;
     int gr = n0 + piece * 8 + rin;
     gr = gr < g.N ? gr : g.N - 1;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.W + (size_t)gr * g.K + koff),
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
   auto issue_next = [&]() {
     int kt_eff = i_kt + i_rot;
     kt_eff = kt_eff >= nk ? kt_eff - nk : kt_eff;
-    g3_stage(g, i_m0, i_n0, kt_eff, lds + (i_it & 1) * G3_STAGE, wid, lane);
+    if ((wid >> 2) == (i_it & 1)) g3_stage(g, i_m0, i_n0, kt_eff, lds + (i_it & 1) * G3_STAGE, wid & 3, lane);
     ++i_it;
     if (++i_kt == nk) {
       i_kt = 0;
@@ -752,10 +756,16 @@ __global__ __launch_bounds__(256) void clip_attn_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int kt = 0; kt < 18; ++kt) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (kt * 16 < S) {  // key tiles entirely past the sequence are never multiplied (uniform branch)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + koff + (((kk * 4 + q4) ^ ksw) << 4));
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], a, 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + koff + (((kk * 4 + q4) ^ ksw) << 4));
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], a, 0, 0, 0);
+        }
+      }
+      if ((kt + 1) * 16 > S) {  // only the tile(s) straddling / past S need the key mask
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = (kt * 16 + q4 * 4 + r) < S ? a[r] : -INFINITY;
       }
       sc[kt] = a;
     }
@@ -764,20 +774,17 @@ __global__ __launch_bounds__(256) void clip_attn_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int kt = 0; kt < 18; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + q4 * 4 + r;
-        const float s = key < S ? sc[kt][r] : -INFINITY;
-        sc[kt][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = 2^(x*scale*log2 e): one v_fma + one v_exp per score
+    const float mc = mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 18; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf((sc[kt][r] - mx) * scale);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c2, -mc));
         sc[kt][r] = p;
         sum += p;
       }

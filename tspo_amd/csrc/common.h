@@ -86,6 +86,10 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even)
+typedef __attribute__((ext_vector_type(2))) float tspo_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 tspo_bf16x2;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const tspo_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, tspo_bf16x2));
 }
