@@ -404,7 +404,7 @@ __device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int 
   }
 }
 
-template <int EPI>
+template <int EPI, int MODE>
 __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int tilesM, int ngrp) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE + 16384];  // the ONLY LDS object
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -456,8 +456,58 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
   int c_kt = 0, c_s = wl;
   for (int it = 0; it < total_it; ++it) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage `it` landed everywhere; buffer (it+1)&1 is free
-    if (i_it < total_it && g.P != -2) issue_next();
     const char* cur = lds + (it & 1) * G3_STAGE;
+    if (MODE == 1) {
+      // default: every wave issues its own 8 pieces, two behind each group of 16 MFMAs of the first half K-step
+      const bool more = i_it < total_it;
+      int kt_eff = i_kt + i_rot;
+      kt_eff = kt_eff >= nk ? kt_eff - nk : kt_eff;
+      char* nbuf = lds + (i_it & 1) * G3_STAGE;
+      const int rin = lane >> 3, slot = lane & 7;
+      const size_t koff = (size_t)kt_eff * GT_BK + ((slot ^ rin) << 3);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int co = (((kk * 4 + q4) ^ sw) << 4);
+        bf16x8 fw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(cur + offW[i] + co);
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp) {
+          bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(cur + offA[2 * mp] + co);
+          bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(cur + offA[2 * mp + 1] + co);
+          if (more && kk == 0) {
+            // the 8 pieces of this wave go out during the FIRST half of the K-step (2 per group of 16 MFMAs) so the
+            // last one still has half a K-step of MFMAs to land behind
+            const int piece = wid * 4 + mp;
+            int gr = i_m0 + piece * 8 + rin;
+            gr = gr < g.M ? gr : g.M - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
+                                             (__attribute__((address_space(3))) void*)(nbuf + piece * 1024), 16, 0, 0);
+            gr = i_n0 + piece * 8 + rin;
+            gr = gr < g.N ? gr : g.N - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.W + (size_t)gr * g.K + koff),
+                                             (__attribute__((address_space(3))) void*)(nbuf + G3_BM * 128 + piece * 1024), 16, 0, 0);
+          }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            acc[ni][2 * mp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa0, acc[ni][2 * mp], 0, 0, 0);
+            acc[ni][2 * mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa1, acc[ni][2 * mp + 1], 0, 0, 0);
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+      if (more) {
+        ++i_it;
+        if (++i_kt == nk) {
+          i_kt = 0;
+          i_s += nwl;
+          i_m0 = ((i_s / n_per) * npset + pset) * G3_BM;
+          i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
+          i_rot = (int)(((long)(i_s % n_per) * nk) / n_per);
+        }
+      }
+    } else {
+    if (i_it < total_it && g.P != -2) issue_next();
     if (g.P > -3)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -472,6 +522,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    }
     }
     if (++c_kt == nk) {
       const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
@@ -519,7 +570,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
   }
 }
 
-template <int EPI>
+template <int EPI, int MODE = 0>
 int launch_gemm_p256(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
   g.tilesN = (g.N + G3_BN - 1) / G3_BN;
@@ -527,7 +578,7 @@ int launch_gemm_p256(GemmArgs g, hipStream_t st) {
   int ngrp = 1;
   const double wbytes = (double)g.N * g.K * 2.0;
   while (ngrp < 8 && wbytes / ngrp > 2.5e6 && g.tilesN % (ngrp * 2) == 0) ngrp *= 2;
-  hipLaunchKernelGGL((gemm_bf16_p256_kernel<EPI>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
+  hipLaunchKernelGGL((gemm_bf16_p256_kernel<EPI, MODE>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
   return tspo::check_launch("gemm_bf16_p256");
 }
 
@@ -540,10 +591,11 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   const bool big = (long)g.M * g.N >= (long)256 * 256 * 256 && g.K >= 128 && g.N <= 4096;
   const int v = g.variant ? g.variant : (big ? 6 : 1);
   if (v == 1) return launch_gemm_v1<EPI>(g, st);
-  if (v == 6) return launch_gemm_p256<EPI>(g, st);
+  if (v == 6) return launch_gemm_p256<EPI, 1>(g, st);
   if (v == 7) { g.P = -2; return launch_gemm_p256<EPI>(g, st); }
   if (v == 8) { g.P = -3; return launch_gemm_p256<EPI>(g, st); }
   if (v == 9) { g.P = -4; return launch_gemm_p256<EPI>(g, st); }
+  if (v == 30) return launch_gemm_p256<EPI, 0>(g, st);   // A/B: all DMA up front, issued by alternating wave rows   // DMA pieces interleaved between MFMA groups
   if (v >= 10 && v < 20) { g.ngrp = v - 10; return launch_gemm_p3<EPI>(g, st); }
   if (v >= 20 && v < 30) { g.ngrp = v - 20; g.P = -3; return launch_gemm_p3<EPI>(g, st); }
   if (v == 3) { g.P = -1; return launch_gemm_p3<EPI>(g, st); }
