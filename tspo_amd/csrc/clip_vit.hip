@@ -749,7 +749,119 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__
 #define AT_VT_STRIDE 592  // bytes per Vt row (296 bf16)
 #define AT_LDS_BYTES (AT_KEYS * 128 + 64 * AT_VT_STRIDE)
 
-__global__ __launch_bounds__(256) void clip_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
+// NQ query tiles (16 queries each, tiles qt and qt+qstride) against all keys of one (frame, head).
+template <int NQ>
+__device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16_t* __restrict__ out, const char* Ks,
+                                           const char* Vt, int S, int C, size_t ld, size_t f, int h, float scale, int qt0,
+                                           int qstride, int l15, int q4) {
+  int voff[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int d = dt * 16 + l15, cd = (d >> 3) & 7;
+    voff[dt][0] = d * AT_VT_STRIDE + ((q4 ^ cd) << 3);
+    voff[dt][1] = d * AT_VT_STRIDE + (((q4 + 4) ^ cd) << 3);
+  }
+  const int koff = l15 * 128;
+  const int ksw = l15 & 7;
+  int qrow[NQ];
+  bool qvalid[NQ];
+  bf16x8 qf[NQ][2];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    const int r = (qt0 + n * qstride) * 16 + l15;
+    qvalid[n] = r < S;
+    qrow[n] = qvalid[n] ? r : S - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[n][kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow[n] * ld + kk * 32 + q4 * 8);
+  }
+  f32x4 sc[NQ][18];
+#pragma unroll
+  for (int kt = 0; kt < 18; ++kt) {
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) sc[n][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (kt * 16 < S) {  // key tiles entirely past the sequence are never multiplied (uniform branch)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + koff + (((kk * 4 + q4) ^ ksw) << 4));
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) sc[n][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[n][kk], sc[n][kt], 0, 0, 0);
+      }
+    }
+    if ((kt + 1) * 16 > S) {  // only the tile(s) straddling / past S need the key mask
+#pragma unroll
+      for (int n = 0; n < NQ; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[n][kt][r] = (kt * 16 + q4 * 4 + r) < S ? sc[n][kt][r] : -INFINITY;
+    }
+  }
+  // softmax over keys: lane holds keys kt*16 + q4*4 + r for query l15
+  const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = 2^(x*scale*log2 e): one v_fma + one v_exp per score
+  float inv[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 18; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[n][kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * c2;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 18; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc[n][kt][r], c2, -mc));
+        sc[n][kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    inv[n] = 1.f / sum;
+  }
+  f32x4 o[NQ][4];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[n][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    union { bf16x8 v; uint32_t u[4]; } pf[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      pf[n].u[0] = pack_bf16x2(sc[n][2 * c][0], sc[n][2 * c][1]);
+      pf[n].u[1] = pack_bf16x2(sc[n][2 * c][2], sc[n][2 * c][3]);
+      pf[n].u[2] = pack_bf16x2(sc[n][2 * c + 1][0], sc[n][2 * c + 1][1]);
+      pf[n].u[3] = pack_bf16x2(sc[n][2 * c + 1][2], sc[n][2 * c + 1][3]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      union { bf16x8 v; uint2 h2[2]; } vf;
+      vf.h2[0] = *reinterpret_cast<const uint2*>(Vt + voff[dt][0] + c * 64);
+      vf.h2[1] = *reinterpret_cast<const uint2*>(Vt + voff[dt][1] + c * 64);
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) o[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[n].v, o[n][dt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    if (qvalid[n]) {
+      bf16_t* orow = out + (f * S + qrow[n]) * (size_t)C + (size_t)h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o[n][dt][0] * inv[n], o[n][dt][1] * inv[n]);
+        pk.y = pack_bf16x2(o[n][dt][2] * inv[n], o[n][dt][3] * inv[n]);
+        *reinterpret_cast<uint2*>(orow + dt * 16 + q4 * 4) = pk;
+      }
+    }
+  }
+}
+
+
+__global__ __launch_bounds__(256, 2) void clip_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
                                                         int C, float scale) {
   __shared__ __attribute__((aligned(16))) char lds[AT_LDS_BYTES];
   char* Ks = lds;
@@ -781,96 +893,18 @@ __global__ __launch_bounds__(256) void clip_attn_kernel(const bf16_t* __restrict
   __syncthreads();
 
   const int nqt = (S + 15) >> 4;
-  // Vt fragment offsets: d = dt*16 + l15, (d>>3)&7 = 2*dt + (l15>>3)
-  int voff[4][2];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    const int d = dt * 16 + l15, cd = (d >> 3) & 7;
-    voff[dt][0] = d * AT_VT_STRIDE + ((q4 ^ cd) << 3);
-    voff[dt][1] = d * AT_VT_STRIDE + (((q4 + 4) ^ cd) << 3);
-  }
-  const int koff = l15 * 128;
-  const int ksw = l15 & 7;
-
-  for (int qt = wid; qt < nqt; qt += 4) {
-    // the K / Vt fragments are loop-invariant; keep the compiler from hoisting ~150 registers of
-    // LDS reads out of this loop (it costs the second wave per SIMD)
-    asm volatile("" ::: "memory");
-    int qrow = qt * 16 + l15;
-    const bool qvalid = qrow < S;
-    qrow = qvalid ? qrow : S - 1;
-    bf16x8 qf[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-      qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 32 + q4 * 8);
-
-    f32x4 sc[18];
-#pragma unroll
-    for (int kt = 0; kt < 18; ++kt) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (kt * 16 < S) {  // key tiles entirely past the sequence are never multiplied (uniform branch)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + koff + (((kk * 4 + q4) ^ ksw) << 4));
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], a, 0, 0, 0);
-        }
-      }
-      if ((kt + 1) * 16 > S) {  // only the tile(s) straddling / past S need the key mask
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = (kt * 16 + q4 * 4 + r) < S ? a[r] : -INFINITY;
-      }
-      sc[kt] = a;
-    }
-    // softmax over keys: lane holds keys kt*16 + q4*4 + r for query l15
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 18; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = 2^(x*scale*log2 e): one v_fma + one v_exp per score
-    const float mc = mx * c2;
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 18; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c2, -mc));
-        sc[kt][r] = p;
-        sum += p;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
-
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      union { bf16x8 v; uint32_t u[4]; } pf;
-      pf.u[0] = pack_bf16x2(sc[2 * c][0], sc[2 * c][1]);
-      pf.u[1] = pack_bf16x2(sc[2 * c][2], sc[2 * c][3]);
-      pf.u[2] = pack_bf16x2(sc[2 * c + 1][0], sc[2 * c + 1][1]);
-      pf.u[3] = pack_bf16x2(sc[2 * c + 1][2], sc[2 * c + 1][3]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        union { bf16x8 v; uint2 h[2]; } vf;
-        vf.h[0] = *reinterpret_cast<const uint2*>(Vt + voff[dt][0] + c * 64);
-        vf.h[1] = *reinterpret_cast<const uint2*>(Vt + voff[dt][1] + c * 64);
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
-      }
-    }
-    if (qvalid) {
-      bf16_t* orow = out + (f * S + qrow) * (size_t)C + (size_t)h * 64;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        uint2 pk;
-        pk.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-        pk.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-        *reinterpret_cast<uint2*>(orow + dt * 16 + q4 * 4) = pk;
-      }
+  // wave w owns query tiles w, w+4, w+8, ...; they are processed two at a time so every K / Vt fragment read from
+  // LDS feeds two MFMAs (LDS bytes per MFMA halve: at one tile per pass the kernel read 1 KB of LDS per MFMA and
+  // was co-limited by LDS bandwidth).
+  int qt = wid;
+  while (qt < nqt) {
+    asm volatile("" ::: "memory");  // keep the loop-invariant K / Vt fragment reads inside the loop (register budget)
+    if (qt + 4 < nqt) {
+      attn_tiles<2>(base, out, Ks, Vt, S, C, ld, f, h, scale, qt, 4, l15, q4);
+      qt += 8;
+    } else {
+      attn_tiles<1>(base, out, Ks, Vt, S, C, ld, f, h, scale, qt, 4, l15, q4);
+      qt += 4;
     }
   }
 }
