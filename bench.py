@@ -96,6 +96,8 @@ def cpu_baseline(T, k, budget_s=20.0):
     w = random_clip_state(c, "cpu")
     sel = random_selector_state(768, "cpu")
     g = torch.Generator().manual_seed(1234)
+    if torch.get_num_threads() > 32:
+        torch.set_num_threads(32)   # measured on the 128-thread EPYC host: 16/32/64/128 threads -> 3.6/3.9/2.9/1.7 frames/s
     cores = torch.get_num_threads()
 
     def enc(n):
@@ -105,9 +107,9 @@ def cpu_baseline(T, k, budget_s=20.0):
             O.clip_vit_forward(w, px, num_heads=c["heads"], patch=c["patch"])
         return time.perf_counter() - t0
 
-    enc(2)                                     # warm-up (thread pool, allocator)
-    t8 = enc(8)
-    n = int(max(8, min(256, (budget_s - 3.0) / (t8 / 8) // 8 * 8)))
+    enc(4)                                     # warm-up (thread pool, allocator)
+    t16 = enc(16)
+    n = int(max(16, min(256, (budget_s - 3.0) / (t16 / 16) // 16 * 16)))
     tn = enc(n)
     feats = torch.randn(T, 768, generator=g)
     txt = torch.randn(1, 768, generator=g)
@@ -136,6 +138,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollouts", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--same-device", action="store_true", help="dry-run aid: every rank uses cuda:0")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = torch default)")
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -143,12 +148,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # RCCL
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(a.backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from tspo_amd import ops
@@ -228,6 +238,8 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        if a.cpu_threads > 0:
+            torch.set_num_threads(a.cpu_threads)
         cpu = cpu_baseline(T, k)
 
     if rank == 0:

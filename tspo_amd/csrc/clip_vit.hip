@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
 
   int i_it = 0, i_kt = 0, i_s = wl;
   int i_m0 = ((i_s / n_per) * npset + pset) * G3_BM, i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
-  int i_rot = (int)(((long)(i_s % n_per) * nk) / n_per);
+  int i_rot = g.P != -6 ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
   auto issue_next = [&]() {
     int kt_eff = i_kt + i_rot;
     kt_eff = kt_eff >= nk ? kt_eff - nk : kt_eff;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
       i_s += nwl;
       i_m0 = ((i_s / n_per) * npset + pset) * G3_BM;
       i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
-      i_rot = (int)(((long)(i_s % n_per) * nk) / n_per);
+      i_rot = g.P != -6 ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
     }
   };
   issue_next();
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
           i_s += nwl;
           i_m0 = ((i_s / n_per) * npset + pset) * G3_BM;
           i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
-          i_rot = (int)(((long)(i_s % n_per) * nk) / n_per);
+          i_rot = g.P != -6 ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
         }
       }
     } else {
@@ -575,9 +575,12 @@ int launch_gemm_p256(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
   g.tilesN = (g.N + G3_BN - 1) / G3_BN;
   g.nwg = tilesM * g.tilesN;
-  int ngrp = 1;
-  const double wbytes = (double)g.N * g.K * 2.0;
-  while (ngrp < 8 && wbytes / ngrp > 2.5e6 && g.tilesN % (ngrp * 2) == 0) ngrp *= 2;
+  // N groups: 2 when W is too big for one XCD's 4 MB L2 and there are enough N tiles to split (measured: QKV 928 vs
+  // 912 TFLOP/s, fc1 875 vs 872; fc2 / out-proj are best un-split).  K-rotation between the workgroups of a panel is
+  // OFF: with it the FETCH_SIZE counter showed ~7 GB of L2 misses for a GEMM whose operands are 0.55 GB (the
+  // workgroups sharing an A panel no longer touched the same lines at the same time), and it ran 6-10 % slower.
+  int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
+  if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
   hipLaunchKernelGGL((gemm_bf16_p256_kernel<EPI, MODE>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
   return tspo::check_launch("gemm_bf16_p256");
 }
@@ -595,7 +598,9 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   if (v == 7) { g.P = -2; return launch_gemm_p256<EPI>(g, st); }
   if (v == 8) { g.P = -3; return launch_gemm_p256<EPI>(g, st); }
   if (v == 9) { g.P = -4; return launch_gemm_p256<EPI>(g, st); }
-  if (v == 30) return launch_gemm_p256<EPI, 0>(g, st);   // A/B: all DMA up front, issued by alternating wave rows   // DMA pieces interleaved between MFMA groups
+  if (v == 30) return launch_gemm_p256<EPI, 0>(g, st);
+  if (v >= 40 && v < 50) { g.ngrp = v - 40; return launch_gemm_p256<EPI, 1>(g, st); }               // forced N groups (0 = auto)
+  if (v >= 50 && v < 60) { g.P = -6; g.ngrp = v - 50; return launch_gemm_p256<EPI, 1>(g, st); }   // K-rotation on, forced N groups   // A/B: all DMA up front, issued by alternating wave rows   // DMA pieces interleaved between MFMA groups
   if (v >= 10 && v < 20) { g.ngrp = v - 10; return launch_gemm_p3<EPI>(g, st); }
   if (v >= 20 && v < 30) { g.ngrp = v - 20; g.P = -3; return launch_gemm_p3<EPI>(g, st); }
   if (v == 3) { g.P = -1; return launch_gemm_p3<EPI>(g, st); }
