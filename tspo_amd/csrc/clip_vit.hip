@@ -54,7 +54,11 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int row
   }
 }
 
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+// x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): one v_exp_f32 + one v_rcp_f32 (1 ulp; the result is rounded
+// to bf16 anyway) instead of a full-precision division sequence
+__device__ __forceinline__ float quick_gelu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
@@ -536,31 +540,46 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
           prow = 1 + (m - f * g.P);
           orow = (size_t)f * (g.P + 1) + prow;
         }
+        uint2 pk[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const int n = n0 + wn * 64 + ni * 16 + q4 * 4;
           f32x4 v = acc[ni][mi];
           acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (m >= g.M || n >= g.N) continue;
-          if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) v += *reinterpret_cast<const f32x4*>(lbias + n);
+          const bool ok = m < g.M && n < g.N;
+          if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) v += *reinterpret_cast<const f32x4*>(lbias + (n < g.N ? n : 0));
           if (EPI == GE_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
           }
-          if (EPI == GE_PATCH) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
           const size_t o = orow * g.N + n;
-          if (EPI == GE_RESID) {
+          if (EPI == GE_PATCH && ok) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
+          if (EPI == GE_RESID && ok) {
             const uint2 rv = *reinterpret_cast<const uint2*>(g.R + o);
             v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
             v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
           }
           if (EPI == GE_F32) {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
+            if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
           } else {
-            uint2 pk;
-            pk.x = pack_bf16x2(v[0], v[1]);
-            pk.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + o) = pk;
+            pk[ni].x = pack_bf16x2(v[0], v[1]);
+            pk[ni].y = pack_bf16x2(v[2], v[3]);
+          }
+        }
+        if (EPI != GE_F32) {
+          // widen the stores: v_permlane16_swap exchanges the odd 16-lane rows of tile a with the even rows of tile
+          // b, after which row q4 holds 16 contiguous bytes of tile (q4 & 1 ? b : a) at column (q4 >> 1) * 8
+          // -> 16 instead of 32 store instructions per wave and tile (the epilogue is store-issue bound)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const auto w0 = __builtin_amdgcn_permlane16_swap(pk[2 * pr].x, pk[2 * pr + 1].x, false, false);
+            const auto w1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr].y, pk[2 * pr + 1].y, false, false);
+            const int n = n0 + wn * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
+            if (m < g.M && n < g.N) {
+              uint4 st;
+              st.x = w0[0]; st.y = w1[0]; st.z = w0[1]; st.w = w1[1];
+              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + orow * g.N + n) = st;
+            }
           }
         }
       }
