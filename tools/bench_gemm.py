@@ -1,12 +1,15 @@
 #!/usr/bin/env python
-"""Micro-benchmark + check of the bf16 MFMA GEMM on the CLIP-L shapes (M = 257*T rows)."""
-import sys, os
+"""Micro-benchmark + check of the bf16 MFMA GEMM on the CLIP-L shapes (M = 257*T rows).
+Variants are timed interleaved (rotating order) over several rounds; the median per variant is reported
+(single back-to-back runs showed an ~8 % position bias)."""
+import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tspo_amd import ops
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2]
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 M = 257 * T
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
@@ -16,28 +19,32 @@ for name, N, K, act, resid in shapes:
     W = (torch.randn(N, K, generator=g, device=dev) * 0.03).to(torch.bfloat16)
     bias = torch.randn(N, generator=g, device=dev) * 0.1
     R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16) if resid else None
-    ref = None
-    for v in variants:
-        f = lambda: ops.gemm_bf16(A, W, bias=bias, residual=R, act=act | (v << 8))
+    rows = torch.randint(0, M, (512,), device=dev)
+    rr = A[rows].float() @ W.float().t() + bias
+    if act == 1:
+        rr = rr * torch.sigmoid(1.702 * rr)
+    if resid:
+        rr = rr + R[rows].float()
+    fns = {v: (lambda v=v: ops.gemm_bf16(A, W, bias=bias, residual=R, act=act | (v << 8))) for v in variants}
+    errs = {}
+    for v, f in fns.items():
         out = f()
         torch.cuda.synchronize()
-        if ref is None:
-            rows = torch.randint(0, M, (512,), device=dev)
-            rr = A[rows].float() @ W.float().t() + bias
-            if act == 1:
-                rr = rr * torch.sigmoid(1.702 * rr)
-            if resid:
-                rr = rr + R[rows].float()
-            ref = (rows, rr)
-        err = (out[ref[0]].float() - ref[1]).abs().max().item() / ref[1].abs().max().item()
-        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
+        errs[v] = (out[rows].float() - rr).abs().max().item() / rr.abs().max().item()
+        for _ in range(2):
             f()
-        st.record()
-        n = 10
-        for _ in range(n):
-            f()
-        en.record()
-        torch.cuda.synchronize()
-        ms = st.elapsed_time(en) / n
-        print(f"{name:4s} N={N:5d} K={K:5d} variant {v}: {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s  relerr {err:.2e}", flush=True)
+    times = {v: [] for v in variants}
+    for r in range(rounds):
+        order = variants[r % len(variants):] + variants[:r % len(variants)]
+        for v in order:
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            for _ in range(5):
+                fns[v]()
+            en.record()
+            torch.cuda.synchronize()
+            times[v].append(st.elapsed_time(en) / 5)
+    for v in variants:
+        ms = statistics.median(times[v])
+        print(f"{name:4s} N={N:5d} K={K:5d} variant {v:3d}: median {ms:7.3f} ms (min {min(times[v]):7.3f})  "
+              f"{2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s  relerr {errs[v]:.2e}", flush=True)

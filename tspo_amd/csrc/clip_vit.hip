@@ -408,9 +408,9 @@ __device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int 
   }
 }
 
-template <int EPI, int MODE>
+template <int EPI, int MODE, int PF>
 __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int tilesM, int ngrp) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE + 16384];  // the ONLY LDS object
+  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE + 16384 + 256];  // the ONLY LDS object (+256 B sink of the L2 prefetch)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, q4 = lane >> 4;
   const int wm = wid >> 2, wn = wid & 3;
@@ -458,12 +458,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
     for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int c_kt = 0, c_s = wl;
+  bool after_epi = true;   // first wait: nothing but the first stage is outstanding
   for (int it = 0; it < total_it; ++it) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage `it` landed everywhere; buffer (it+1)&1 is free
+    // stage `it` landed everywhere; buffer (it+1)&1 is free.  Wave 0 may leave its 4 (younger) L2-prefetch ops in flight,
+    // except right after an epilogue whose stores are younger still.
+    if (PF > 0 && (wid == 0 || (PF > 100 && wid == 1)) && !after_epi) {
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if (g.P != -7) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    after_epi = false;
     const char* cur = lds + (it & 1) * G3_STAGE;
     if (MODE == 1) {
       // default: every wave issues its own 8 pieces, two behind each group of 16 MFMAs of the first half K-step
-      const bool more = i_it < total_it;
+      const bool more = i_it < total_it && g.P > -2;
       int kt_eff = i_kt + i_rot;
       kt_eff = kt_eff >= nk ? kt_eff - nk : kt_eff;
       char* nbuf = lds + (i_it & 1) * G3_STAGE;
@@ -496,6 +504,48 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
           for (int ni = 0; ni < 4; ++ni) {
             acc[ni][2 * mp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa0, acc[ni][2 * mp], 0, 0, 0);
             acc[ni][2 * mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa1, acc[ni][2 * mp + 1], 0, 0, 0);
+          }
+          if (PF > 100 && more && kk == 0 && mp == 3 && wid == 1) {   // A/B probe: also prefetch the W slice (wave 1)
+            int p_kt = i_kt + (PF - 100), p_n0 = i_n0;
+            const bool pv = i_it + (PF - 100) < total_it;
+            if (p_kt >= nk) {
+              p_kt -= nk;
+              const int s2 = i_s + nwl;
+              p_n0 = (grp * n_per + s2 % n_per) * G3_BN;
+            }
+            if (pv) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                int gr = p_n0 + j * 64 + lane;
+                gr = gr < g.N ? gr : g.N - 1;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(g.W + (size_t)gr * g.K + (size_t)p_kt * GT_BK),
+                    (__attribute__((address_space(3))) void*)(lds + 2 * G3_STAGE + 16384), 4, 0, 0);
+              }
+            }
+          }
+          if (PF > 0 && more && kk == 0 && mp == 3 && wid == 0) {
+            // L2 prefetch of the A slice this workgroup will stage PF K-steps from now: one 4-byte LDS-DMA per
+            // 128-B line (64 lines per instruction, destination = a 256-B sink), so the real 16-B pieces issued PF
+            // steps later find the first-touch lines of the panel in L2 instead of waiting on HBM
+            const int PFD = PF > 100 ? PF - 100 : PF;
+            int p_kt = i_kt + PFD, p_m0 = i_m0;
+            bool pv = i_it + PFD < total_it;
+            if (p_kt >= nk) {
+              p_kt -= nk;
+              const int s2 = i_s + nwl;
+              p_m0 = ((s2 / n_per) * npset + pset) * G3_BM;
+            }
+            if (pv) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                int gr = p_m0 + j * 64 + lane;
+                gr = gr < g.M ? gr : g.M - 1;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + (size_t)p_kt * GT_BK),
+                    (__attribute__((address_space(3))) void*)(lds + 2 * G3_STAGE + 16384), 4, 0, 0);
+              }
+            }
           }
           asm volatile("" ::: "memory");
         }
@@ -585,11 +635,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
       }
       c_kt = 0;
       c_s += nwl;
+      after_epi = true;
     }
   }
 }
 
-template <int EPI, int MODE = 0>
+template <int EPI, int MODE = 0, int PF = 0>
 int launch_gemm_p256(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
   g.tilesN = (g.N + G3_BN - 1) / G3_BN;
@@ -600,7 +651,7 @@ int launch_gemm_p256(GemmArgs g, hipStream_t st) {
   // workgroups sharing an A panel no longer touched the same lines at the same time), and it ran 6-10 % slower.
   int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
   if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
-  hipLaunchKernelGGL((gemm_bf16_p256_kernel<EPI, MODE>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
+  hipLaunchKernelGGL((gemm_bf16_p256_kernel<EPI, MODE, PF>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
   return tspo::check_launch("gemm_bf16_p256");
 }
 
@@ -613,8 +664,13 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   const bool big = (long)g.M * g.N >= (long)256 * 256 * 256 && g.K >= 128 && g.N <= 4096;
   const int v = g.variant ? g.variant : (big ? 6 : 1);
   if (v == 1) return launch_gemm_v1<EPI>(g, st);
-  if (v == 6) return launch_gemm_p256<EPI, 1>(g, st);
-  if (v == 7) { g.P = -2; return launch_gemm_p256<EPI>(g, st); }
+  if (v == 6) return launch_gemm_p256<EPI, 1, 6>(g, st);     // default: interleaved DMA issue + L2 prefetch of A 6 K-steps ahead
+  if (v == 65) return launch_gemm_p256<EPI, 1, 0>(g, st);    // A/B: no L2 prefetch
+  if (v == 7) { g.P = -2; return launch_gemm_p256<EPI, 1>(g, st); }
+  if (v == 60) { g.P = -7; return launch_gemm_p256<EPI, 1>(g, st); }
+  if (v == 61) return launch_gemm_p256<EPI, 1, 3>(g, st);   // + L2 prefetch of A, 3 K-steps ahead
+  if (v == 63) return launch_gemm_p256<EPI, 1, 12>(g, st);
+  if (v == 64) return launch_gemm_p256<EPI, 1, 106>(g, st);  // A and W prefetch, 6 ahead   // compute only, no barrier (timing probe; wrong results)
   if (v == 8) { g.P = -3; return launch_gemm_p256<EPI>(g, st); }
   if (v == 9) { g.P = -4; return launch_gemm_p256<EPI>(g, st); }
   if (v == 30) return launch_gemm_p256<EPI, 0>(g, st);
