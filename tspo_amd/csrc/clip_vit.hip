@@ -700,7 +700,9 @@ int gemm_dispatch(int epi, const GemmArgs& g, hipStream_t st) {
 // row lives in registers (16-byte loads), two-pass mean / variance in fp32.
 // in_stride / out_stride in elements (lets the post-LN read only CLS rows).
 // ===========================================================================
-#define LN_MAXCH 8
+// LN_MAXCH = ceil(C / 512) 16-byte chunks per lane: a template parameter so that C = 1024 needs 16 value registers
+// (8 waves/SIMD resident = twice the bytes in flight of the generic C <= 4096 instance).
+template <int LN_MAXCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* in, bf16_t* out,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         long rows, int C, long in_stride, long out_stride, float eps) {
@@ -1059,8 +1061,10 @@ struct Prof {
 
 int run_ln(const bf16_t* in, bf16_t* out, const float* g, const float* b, long rows, int C, long is, long os, float eps,
            hipStream_t st) {
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, in, out, g, b, rows, C, is, os,
-                     eps);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, in, out, g, b, rows, C, is, os, eps);
+  else if (C <= 2048) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, in, out, g, b, rows, C, is, os, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, in, out, g, b, rows, C, is, os, eps);
   return tspo::check_launch("layernorm");
 }
 
