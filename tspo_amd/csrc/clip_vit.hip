@@ -819,30 +819,31 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__
 
 // ===========================================================================
 // Attention for one (frame, head): S <= 288 tokens, head_dim 64, non-causal.
-// K rows in LDS (swizzled like the GEMM tiles), V transposed in LDS (Vt[d][key],
-// 4-key groups XOR-swizzled by d>>3 so both the scattered b16 writes and the
-// b64 fragment reads spread over the banks).  Each wave owns 16-query tiles:
+// K rows in LDS (swizzled like the GEMM tiles), V row-major in [32 keys][16 d] sub-tiles that the
+// hardware transpose read (ds_read_b64_tr_b16) turns into V^T fragments.  Each wave owns 16-query tiles:
 //   S^T = K Q^T  (18 key tiles -> 72 fp32 regs hold the full score row)
 //   softmax over keys in registers (lane-local + 2 xor-shuffles)
 //   O^T = V^T P^T with P taken straight from the S^T accumulators (the key
 //   permutation inside each 32-key chunk is shared by both MFMA operands).
 // ===========================================================================
 #define AT_KEYS 288
-#define AT_VT_STRIDE 592  // bytes per Vt row (296 bf16)
-#define AT_LDS_BYTES (AT_KEYS * 128 + 64 * AT_VT_STRIDE)
+#define AT_V_BYTES (9 * 4 * 1024)  // V: 9 key chunks x 4 d-tiles of row-major [32 keys][16 d] sub-tiles (1 KB each)
+#define AT_LDS_BYTES (AT_KEYS * 128 + AT_V_BYTES)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // NQ query tiles (16 queries each, tiles qt and qt+qstride) against all keys of one (frame, head).
 template <int NQ>
 __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16_t* __restrict__ out, const char* Ks,
                                            const char* Vt, int S, int C, size_t ld, size_t f, int h, float scale, int qt0,
                                            int qstride, int l15, int q4) {
+  // V^T fragments come from ds_read_b64_tr_b16: the 16 lanes of a row each point at 4 contiguous bf16 of a
+  // row-major [4 keys][16 d] block (lane i -> key i>>2, d-chunk i&3) and receive COLUMN i of it, i.e. 4 keys of
+  // their own d - so V stays row-major in LDS (16-byte staging writes, no scattered 2-byte transposition).
   int voff[4][2];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    const int d = dt * 16 + l15, cd = (d >> 3) & 7;
-    voff[dt][0] = d * AT_VT_STRIDE + ((q4 ^ cd) << 3);
-    voff[dt][1] = d * AT_VT_STRIDE + (((q4 + 4) ^ cd) << 3);
-  }
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) voff[dt][hh] = dt * 1024 + (hh * 16 + q4 * 4 + (l15 >> 2)) * 32 + (l15 & 3) * 8;
   const int koff = l15 * 128;
   const int ksw = l15 & 7;
   int qrow[NQ];
@@ -920,9 +921,9 @@ __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      union { bf16x8 v; uint2 h2[2]; } vf;
-      vf.h2[0] = *reinterpret_cast<const uint2*>(Vt + voff[dt][0] + c * 64);
-      vf.h2[1] = *reinterpret_cast<const uint2*>(Vt + voff[dt][1] + c * 64);
+      union { bf16x8 v; s16x4 h2[2]; } vf;
+      vf.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vt + voff[dt][0] + c * 4096));
+      vf.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vt + voff[dt][1] + c * 4096));
 #pragma unroll
       for (int n = 0; n < NQ; ++n) o[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[n].v, o[n][dt], 0, 0, 0);
     }
@@ -964,13 +965,7 @@ __global__ __launch_bounds__(256, 2) void clip_attn_kernel(const bf16_t* __restr
       vv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + 2 * C + c * 8);
     }
     *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kv;
-    const int kpos = ((((row >> 2) ^ c) << 2) | (row & 3)) * 2;  // byte offset of this key inside a Vt row for d>>3 == c
-    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const uint16_t val = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffff));
-      *reinterpret_cast<uint16_t*>(Vt + (c * 8 + e) * AT_VT_STRIDE + kpos) = val;
-    }
+    *reinterpret_cast<uint4*>(Vt + ((row >> 5) * 4 + (c >> 1)) * 1024 + (row & 31) * 32 + (c & 1) * 16) = vv;
   }
   __syncthreads();
 
