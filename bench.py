@@ -37,6 +37,21 @@ def gemm_flops_per_frame(c):
     return patch + c["layers"] * layer + 2 * C * c["proj"]
 
 
+def alg_bytes_per_launch(c, n_frames):
+    """Algorithmic HBM bytes of the encoder GEMMs averaged over the launches of one encode: each operand read
+    once, each output written once (bf16 activations, bf16 weights)."""
+    S = (c["image"] // c["patch"]) ** 2 + 1
+    M, C, mlp = S * n_frames, c["hidden"], c["mlp"]
+    qkv = 2 * (M * C + 3 * C * C + M * 3 * C)
+    out = 2 * (M * C + C * C + 2 * M * C)            # + residual read
+    fc1 = 2 * (M * C + mlp * C + M * mlp)
+    fc2 = 2 * (M * mlp + mlp * C + 2 * M * C)
+    kp = (3 * c["patch"] ** 2 + 63) // 64 * 64
+    patch = 2 * ((M - n_frames) * kp + C * kp + (M - n_frames) * C)
+    proj = 2 * (n_frames * C + c["proj"] * C) + 4 * n_frames * c["proj"]
+    return (c["layers"] * (qkv + out + fc1 + fc2) + patch + proj) / (4 * c["layers"] + 2)
+
+
 def attn_flops_per_frame(c):
     S = (c["image"] // c["patch"]) ** 2 + 1
     return c["layers"] * 2 * 2 * S * S * c["hidden"]
@@ -228,8 +243,19 @@ def main():
         pr = ops.clip_vit_profile(clipw, px)
         gflop = gemm_flops_per_frame(c) * B * T
         ach = gflop / (pr["gemm_ms"] * 1e-3) / 1e12
+        # HBM-side bytes per GEMM launch: cannot be read from inside the process; taken from the committed PMC passes
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, tools/pmc_traffic.py) when they match this config
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "r1_gemm_hbm_traffic_T1024.json")
+        if os.path.exists(tpath) and B * T == 1024:
+            try:
+                tj = json.load(open(tpath))
+                traffic, tsrc = tj["hbm_bytes_per_launch_avg"], "profiles/r1_gemm_hbm_traffic_T1024.json"
+            except Exception:
+                pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "gemm_bf16_kernel",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "alg_bytes_per_launch_avg": alg_bytes_per_launch(c, B * T), "kernel": "gemm_bf16_p256_kernel",
                 "launches_per_step": pr["gemm_launches"],
                 "avg_launch_ms": round(pr["gemm_ms"] / pr["gemm_launches"], 4),
                 "alg_flop_per_launch_avg": gflop / pr["gemm_launches"],

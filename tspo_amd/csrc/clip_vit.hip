@@ -408,7 +408,7 @@ __device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int 
   }
 }
 
-template <int EPI, int MODE, int PF>
+template <int EPI, int MODE, int PF, int EARLY>
 __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int tilesM, int ngrp) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE + 16384 + 256];  // the ONLY LDS object (+256 B sink of the L2 prefetch)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -487,10 +487,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
         for (int mp = 0; mp < 4; ++mp) {
           bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(cur + offA[2 * mp] + co);
           bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(cur + offA[2 * mp + 1] + co);
-          if (more && kk == 0) {
+          if (more && kk == 0 && (EARLY == 0 || mp < 2))
+#pragma unroll
+          for (int e = 0; e < (EARLY ? 2 : 1); ++e) {
             // the 8 pieces of this wave go out during the FIRST half of the K-step (2 per group of 16 MFMAs) so the
-            // last one still has half a K-step of MFMAs to land behind
-            const int piece = wid * 4 + mp;
+            // last one still has half a K-step of MFMAs to land behind  (EARLY: 4 per group, first quarter)
+            const int piece = wid * 4 + (EARLY ? mp * 2 + e : mp);
             int gr = i_m0 + piece * 8 + rin;
             gr = gr < g.M ? gr : g.M - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
   }
 }
 
-template <int EPI, int MODE = 0, int PF = 0>
+template <int EPI, int MODE = 0, int PF = 0, int EARLY = 0>
 int launch_gemm_p256(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
   g.tilesN = (g.N + G3_BN - 1) / G3_BN;
@@ -651,7 +653,7 @@ int launch_gemm_p256(GemmArgs g, hipStream_t st) {
   // workgroups sharing an A panel no longer touched the same lines at the same time), and it ran 6-10 % slower.
   int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
   if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
-  hipLaunchKernelGGL((gemm_bf16_p256_kernel<EPI, MODE, PF>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
+  hipLaunchKernelGGL((gemm_bf16_p256_kernel<EPI, MODE, PF, EARLY>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
   return tspo::check_launch("gemm_bf16_p256");
 }
 
@@ -666,6 +668,7 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   if (v == 1) return launch_gemm_v1<EPI>(g, st);
   if (v == 6) return launch_gemm_p256<EPI, 1, 6>(g, st);     // default: interleaved DMA issue + L2 prefetch of A 6 K-steps ahead
   if (v == 65) return launch_gemm_p256<EPI, 1, 0>(g, st);    // A/B: no L2 prefetch
+  if (v == 66) return launch_gemm_p256<EPI, 1, 6, 1>(g, st); // A/B: DMA pieces issued in the first quarter of the K-step
   if (v == 7) { g.P = -2; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 60) { g.P = -7; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 61) return launch_gemm_p256<EPI, 1, 3>(g, st);   // + L2 prefetch of A, 3 K-steps ahead
