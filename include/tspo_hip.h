@@ -222,6 +222,20 @@ int tspo_clip_vit_profile(const tspo_clip_weights* w, const void* pixels, int pi
                           float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
                           float* host_ms6);
 
+/* On-device CLIPImageProcessor front half: uint8 frames [T,H,W,3] (layout 0) or [T,3,H,W] (layout 1) ->
+ * Pillow-exact antialiased bicubic resize + centre crop -> uint8 [T,3,out_h,out_w].  Replaces the per-frame
+ * np.array -> PIL.Image -> clip_processor loop of model/temporal_agent.py:156-164 (and tspo_trainer.py:393-399).
+ * hcoef/vcoef: int32 [out][k] fixed-point (22 fractional bits) filter taps; hbound/vbound: int32 [out][2] =
+ * (first input index, tap count), for the output columns / rows of the crop window only (built on the host by
+ * tspo_amd/preprocess.py exactly as Pillow's precompute_coeffs + normalize_coeffs_8bpc).  [ylo, ylo+nrows) is the
+ * range of input rows the vertical taps touch.  Bit-exact with PIL.                                        */
+size_t tspo_preprocess_workspace_bytes(int T, int nrows, int out_w);
+int tspo_preprocess_frames(const uint8_t* frames, int layout, int T, int H, int W,
+                           const int32_t* hcoef, const int32_t* hbound, int out_w, int hk,
+                           const int32_t* vcoef, const int32_t* vbound, int out_h, int vk,
+                           int ylo, int nrows, uint8_t* out,
+                           void* workspace, size_t workspace_bytes, tspo_stream_t stream);
+
 /* torch.nn.CosineSimilarity(dim=-1)(text[b,0,:], feat[b,t,:])  (temporal_agent.py:167).
  * txt f32 [B,M,D] (row 0 of each prompt is used), feat f32 [B,T,D] -> clip f32 [B,T]. */
 int tspo_clip_scores(const float* txt, const float* feat, int B, int T, int D, int M, float* clip,

@@ -441,3 +441,83 @@ def frames_scored_path(clip_w, sel_params, pixels, text_features, *, num_heads, 
     clip = clip_cosine_scores(text_features, feats)
     scores, _ = selector_forward(sel_params, feats, text_features, clip, window_size, tau)
     return topk_sorted(scores, k), scores, feats
+
+
+# --------------------------------------------------------------------------
+# K1  CLIPImageProcessor front half: PIL antialiased bicubic resize + centre crop
+#     (third-party: Pillow src/libImaging/Resample.c, transformers CLIPImageProcessor;
+#      reference call sites model/temporal_agent.py:156-164, tspo_trainer.py:393-399)
+# --------------------------------------------------------------------------
+
+def _pil_bicubic(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def _pil_coeffs(in_size: int, out_size: int):
+    """precompute_coeffs + normalize_coeffs_8bpc (PRECISION_BITS = 22)."""
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = 2.0 * fs
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), np.int64)
+    bounds = np.zeros((out_size, 2), np.int64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_pil_bicubic((x + xmin - center + 0.5) * (1.0 / fs)) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x, v in enumerate(w):
+            v = v / ww if ww != 0.0 else v
+            kk[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return kk, bounds
+
+
+def _pil_resample_axis(img: np.ndarray, out_size: int, axis: int) -> np.ndarray:
+    a = np.moveaxis(img, axis, 0).astype(np.int64)
+    kk, b = _pil_coeffs(a.shape[0], out_size)
+    out = np.zeros((out_size,) + a.shape[1:], np.int64)
+    for xx in range(out_size):
+        xmin, xmax = b[xx]
+        acc = np.full(a.shape[1:], 1 << 21, np.int64)
+        for x in range(xmax):
+            acc += a[xmin + x] * kk[xx, x]
+        out[xx] = np.clip(acc >> 22, 0, 255)
+    return np.moveaxis(out.astype(np.uint8), 0, axis)
+
+
+def pil_bicubic_resize_u8(img: np.ndarray, new_w: int, new_h: int) -> np.ndarray:
+    """uint8 [H,W,C] -> [new_h,new_w,C], bit-identical to PIL.Image.resize(..., BICUBIC): horizontal pass into a
+    rounded uint8 image, then vertical pass; a pass whose size does not change is skipped."""
+    h, w = img.shape[:2]
+    out = img
+    if new_w != w:
+        out = _pil_resample_axis(out, new_w, 1)
+    if new_h != h:
+        out = _pil_resample_axis(out, new_h, 0)
+    return out
+
+
+def clip_preprocess_u8(frames: np.ndarray, size: int = 224) -> np.ndarray:
+    """uint8 [T,H,W,3] -> uint8 [T,3,size,size]: CLIPImageProcessor's resize(shortest_edge) + center_crop
+    (rescale / normalise are applied afterwards: clip_normalize_pixels)."""
+    T, H, W, _ = frames.shape
+    short, long = (W, H) if W <= H else (H, W)
+    new_short, new_long = size, int(size * long / short)
+    new_w, new_h = (new_short, new_long) if W <= H else (new_long, new_short)
+    top, left = (new_h - size) // 2, (new_w - size) // 2
+    out = np.zeros((T, 3, size, size), np.uint8)
+    for t in range(T):
+        r = pil_bicubic_resize_u8(frames[t], new_w, new_h)
+        out[t] = r[top:top + size, left:left + size].transpose(2, 0, 1)
+    return out

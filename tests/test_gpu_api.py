@@ -174,6 +174,7 @@ class _StubProcessor:
     def __init__(self):
         from transformers import CLIPImageProcessor
         self.ip = CLIPImageProcessor()
+        self.image_processor = self.ip      # like CLIPProcessor: enables the on-device preprocessing path
 
     def __call__(self, text=None, images=None, return_tensors="pt", **kw):
         from transformers import BatchEncoding, BatchFeature
@@ -219,6 +220,11 @@ def test_tspo_model_end_to_end_small_config():
     chw = [torch.from_numpy(f).permute(2, 0, 1) for f in frames]
     f2, _, _ = model.extract_feature(proc, chw, "what is shown?", processor_type="qwen25vl")
     assert torch.equal(f2, feats)
+    # on-device preprocessing (Pillow-exact) == the CPU PIL path of the reference: identical features
+    proc_cpu = _StubProcessor()
+    del proc_cpu.image_processor
+    f3, _, _ = model.extract_feature(proc_cpu, frames, "what is shown?")
+    assert (f3.float() - feats.float()).abs().max().item() <= 2e-2 * feats.float().abs().max().item()
 
 
 def test_full_size_properties_T1024():

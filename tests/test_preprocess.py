@@ -1,0 +1,79 @@
+"""K1: on-device CLIP image preprocessing.  CPU part: the oracle restatement and the host tap tables against
+Pillow / transformers' CLIPImageProcessor (bit-exact).  GPU part: the HIP kernel against the oracle (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tspo_oracle as O
+from tspo_amd import preprocess as P, synth
+
+SIZES = [(360, 640), (480, 360), (224, 224), (300, 224), (200, 150), (225, 400), (1080, 1920), (230, 231)]
+
+
+@pytest.mark.parametrize("hw", SIZES[:6], ids=[f"{h}x{w}" for h, w in SIZES[:6]])
+def test_oracle_matches_pil_and_clip_processor(hw):
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    H, W = hw
+    frames = synth.uniform_u8((2, H, W, 3), 100 + H)
+    new_h, new_w, top, left = P.clip_resize_geometry(H, W)
+    for t in range(2):
+        ref = np.array(Image.fromarray(frames[t]).resize((new_w, new_h), resample=Image.BICUBIC))
+        np.testing.assert_array_equal(O.pil_bicubic_resize_u8(frames[t], new_w, new_h), ref)
+    got = O.clip_preprocess_u8(frames)
+    proc = CLIPImageProcessor()
+    assert P.processor_is_default_clip(proc)
+    pv = proc(images=[Image.fromarray(f) for f in frames], return_tensors="pt")["pixel_values"]
+    mine = O.clip_normalize_pixels(torch.from_numpy(got))
+    np.testing.assert_allclose(mine.numpy(), pv.numpy(), rtol=0, atol=2e-6)
+
+
+def test_host_tables_reproduce_oracle():
+    """numpy evaluation of the exact integer arithmetic the kernel performs, with the product's tap tables."""
+    for H, W in SIZES:
+        frames = synth.uniform_u8((1, H, W, 3), 7 + W)
+        hk, hb, vk, vb, ylo, nrows = P._tables(H, W, 224)
+        img = frames[0].astype(np.int64)
+        tmp = np.zeros((nrows, 224, 3), np.int64)
+        for x in range(224):
+            acc = np.full((nrows, 3), 1 << 21, np.int64)
+            for i in range(hb[x, 1]):
+                acc += img[ylo:ylo + nrows, hb[x, 0] + i] * int(hk[x, i])
+            tmp[:, x] = np.clip(acc >> 22, 0, 255)
+        out = np.zeros((224, 224, 3), np.int64)
+        for y in range(224):
+            acc = np.full((224, 3), 1 << 21, np.int64)
+            for i in range(vb[y, 1]):
+                acc += tmp[vb[y, 0] - ylo + i] * int(vk[y, i])
+            out[y] = np.clip(acc >> 22, 0, 255)
+        np.testing.assert_array_equal(out.transpose(2, 0, 1).astype(np.uint8), O.clip_preprocess_u8(frames)[0])
+
+
+def test_processor_config_detection():
+    from transformers import CLIPImageProcessor
+    assert P.processor_is_default_clip(CLIPImageProcessor())
+    assert not P.processor_is_default_clip(CLIPImageProcessor(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336}))
+    assert not P.processor_is_default_clip(CLIPImageProcessor(resample=2))
+    assert not P.processor_is_default_clip(object())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", SIZES, ids=[f"{h}x{w}" for h, w in SIZES])
+def test_gpu_preprocess_bit_exact(hw):
+    H, W = hw
+    T = 3
+    frames = synth.uniform_u8((T, H, W, 3), 55 + H + W)
+    ref = O.clip_preprocess_u8(frames)
+    got = P.preprocess_frames(torch.from_numpy(frames).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    chw = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 3, 1, 2))).cuda()     # qwen25vl-style [T,3,H,W]
+    np.testing.assert_array_equal(P.preprocess_frames(chw).cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_rejects_bad_input():
+    from tspo_amd._lib import TspoHipError
+    with pytest.raises(TspoHipError):
+        P.preprocess_frames(torch.zeros(2, 8, 8, 3, dtype=torch.uint8))
+    with pytest.raises(TypeError):
+        P.preprocess_frames(torch.zeros(2, 8, 8, 3, device="cuda"))

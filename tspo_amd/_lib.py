@@ -60,6 +60,8 @@ SIGNATURES = {
     "tspo_clip_workspace_bytes": (_sz, [C.POINTER(ClipConfig), _i]),
     "tspo_clip_vit_forward": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p]),
     "tspo_clip_vit_profile": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p, C.POINTER(C.c_float)]),
+    "tspo_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
+    "tspo_preprocess_frames": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "tspo_clip_scores": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "tspo_gemm_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }

@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtspo_hip.so")
-SOURCES = ["sampler.hip", "selector.hip", "clip_vit.hip"]
+SOURCES = ["sampler.hip", "selector.hip", "clip_vit.hip", "preprocess.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "tspo_hip.h")]
 
 

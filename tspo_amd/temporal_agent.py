@@ -224,6 +224,27 @@ def _frames_to_pil(candidates, processor_type):
     return image_list
 
 
+def _frames_to_device_u8(candidates, processor_type, dev, clip_processor):
+    """uint8 frames -> GPU -> Pillow-exact resize/crop in HIP (tspo_preprocess_frames) -> uint8 [T,3,224,224]; the
+    normalisation is fused into the encoder's patch gather.  Returns None when the processor is not configured like
+    CLIP's default one or the frames are not a uniform uint8 batch (then the PIL path of the reference is used)."""
+    from .preprocess import preprocess_frames, processor_is_default_clip
+    ip = getattr(clip_processor, "image_processor", None)
+    if ip is None or not processor_is_default_clip(ip):
+        return None
+    try:
+        if processor_type == 'llava':
+            arr = candidates if isinstance(candidates, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(candidates)))
+        else:
+            arr = torch.stack([c for c in candidates]) if not isinstance(candidates, torch.Tensor) else candidates
+            arr = arr.to(torch.uint8) if arr.dtype != torch.uint8 else arr
+        if arr.dtype != torch.uint8 or arr.ndim != 4:
+            return None
+        return preprocess_frames(arr.to(dev))
+    except (ValueError, TypeError, RuntimeError):
+        return None
+
+
 def extract_clip_features_impl(clip_model, clip_processor, candidates, problem, processor_type='llava'):
     """temporal_agent.py:151-169 / utils.py:18-35 / tspo_trainer.py:387-404: text tower on stock
     PyTorch-ROCm, all T frames through the HIP CLIP encoder, cosine clip score in HIP."""
@@ -231,10 +252,12 @@ def extract_clip_features_impl(clip_model, clip_processor, candidates, problem, 
     inputs_text = clip_processor(text=problem, return_tensors="pt", padding=True, truncation=True).to(dev)
     with torch.no_grad():
         text_features = _pooled(clip_model.get_text_features(**inputs_text))
-    image_list = _frames_to_pil(candidates, processor_type)
-    inputs_image = clip_processor(images=image_list, return_tensors="pt", padding=True).to(dev)
+    pixels = _frames_to_device_u8(candidates, processor_type, dev, clip_processor)
+    if pixels is None:   # non-default processor config / ragged frames: the reference's own CPU PIL path
+        image_list = _frames_to_pil(candidates, processor_type)
+        pixels = clip_processor(images=image_list, return_tensors="pt", padding=True).to(dev)["pixel_values"]
     with torch.no_grad():
-        image_features = _image_features(clip_model, inputs_image["pixel_values"])
+        image_features = _image_features(clip_model, pixels)
         clip_scores = ops.clip_scores(text_features[:1].float().unsqueeze(0), image_features.unsqueeze(0))[0]
     dt = clip_model.dtype
     return image_features.to(dt), text_features, clip_scores.to(dt)
