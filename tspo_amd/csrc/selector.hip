@@ -58,20 +58,42 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    f32x4 a[2], b[2];
+  // software pipeline, prefetch distance 2 K-steps (the problem is L2 resident but only ~2 waves share a SIMD, so
+  // an un-prefetched loop exposes the whole L2 latency every 16 MFMAs: measured 34 % of the fp32 MFMA peak)
+  // Loads past the end re-read the last K-step (clamped address, result unused): keeping the loads unconditional lets
+  // the compiler emit counted vmcnt waits - with branches around them it falls back to vmcnt(0) and the prefetch is lost.
+  f32x4 a0[2], b0[2], a1[2], b1[2], a2[2], b2[2];
+  const int klast = K - 16;
+  auto ld = [&](f32x4 (&a)[2], f32x4 (&b)[2], int k0) {
+    k0 = k0 < klast ? k0 : klast;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       a[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
       b[i] = *reinterpret_cast<const f32x4*>(wp[i] + k0);
     }
+  };
+  auto mm = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+  };
+  ld(a0, b0, 0);
+  ld(a1, b1, 16);
+  const int nsteps = K >> 4;
+  int st = 0;
+  for (; st + 3 <= nsteps; st += 3) {   // three register sets rotate; prefetch distance 2 K-steps
+    ld(a2, b2, (st + 2) << 4);
+    mm(a0, b0);
+    ld(a0, b0, (st + 3) << 4);
+    mm(a1, b1);
+    ld(a1, b1, (st + 4) << 4);
+    mm(a2, b2);
   }
+  if (st < nsteps) mm(a0, b0);
+  if (st + 1 < nsteps) mm(a1, b1);
   // D layout: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -366,17 +388,38 @@ __global__ __launch_bounds__(256) void gemm_f32_tn_kernel(const float* __restric
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float* yp = dY + i0 + 4 * l15;
   const float* xp = X + j0 + 4 * l15;
-  for (int m = mb; m < me; m += 4) {
+  // rows past the chunk end are clamped and their contribution zeroed by a multiplier (no branch around the loads,
+  // so the compiler keeps counted vmcnt waits and the prefetch distance of 2 survives)
+  const int rlast = me > mb ? me - 1 : mb;
+  auto ld = [&](f32x4& a, f32x4& b, int m) {
     const int r = m + q;
-    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a;
-    if (r < me) {
-      a = *reinterpret_cast<const f32x4*>(yp + (size_t)r * NI);
-      b = *reinterpret_cast<const f32x4*>(xp + (size_t)r * NJ);
-    }
+    const int rc = r < rlast ? r : rlast;
+    const float keep = (r < me) ? 1.f : 0.f;
+    a = *reinterpret_cast<const f32x4*>(yp + (size_t)rc * NI) * keep;
+    b = *reinterpret_cast<const f32x4*>(xp + (size_t)rc * NJ);
+  };
+  auto mm = [&](const f32x4& a, const f32x4& b) {
 #pragma unroll
     for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ca], b[cb], acc[ca][cb], 0, 0, 0);
+  };
+  f32x4 a0, b0, a1, b1, a2, b2;
+  if (me > mb) {
+    ld(a0, b0, mb);
+    ld(a1, b1, mb + 4);
+    const int nsteps = (me - mb + 3) >> 2;
+    int st = 0;
+    for (; st + 3 <= nsteps; st += 3) {
+      ld(a2, b2, mb + ((st + 2) << 2));
+      mm(a0, b0);
+      ld(a0, b0, mb + ((st + 3) << 2));
+      mm(a1, b1);
+      ld(a1, b1, mb + ((st + 4) << 2));
+      mm(a2, b2);
+    }
+    if (st < nsteps) mm(a0, b0);
+    if (st + 1 < nsteps) mm(a1, b1);
   }
   float* cp = Cp + (size_t)s * NI * NJ;
 #pragma unroll
