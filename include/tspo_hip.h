@@ -243,7 +243,9 @@ int tspo_clip_scores(const float* txt, const float* feat, int B, int T, int D, i
 
 /* Generic bf16 MFMA GEMM exposed for tests / micro-benchmarks:
  * C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, f32 accumulate, out bf16 or f32.
- * K % 64 == 0.  act: 0 none, 1 quick_gelu.  residual (bf16 [M,N], nullable) is added. */
+ * K % 64 == 0.  act (bits 0-7): 0 none, 1 quick_gelu.  residual (bf16 [M,N], nullable) is added.
+ * Bits 8+ of `act` select a kernel variant for A/B tests and ablations (tools/bench_gemm.py; some ablation
+ * variants deliberately compute wrong results) - production callers pass 0 there.                          */
 int tspo_gemm_bf16(const void* A, const void* W, const float* bias, const void* residual,
                    void* C, int out_dtype, int M, int N, int K, int act, tspo_stream_t stream);
 

@@ -487,12 +487,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
         for (int mp = 0; mp < 4; ++mp) {
           bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(cur + offA[2 * mp] + co);
           bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(cur + offA[2 * mp + 1] + co);
-          if (more && kk == 0 && (EARLY == 0 || mp < 2))
+          if (more && kk == 0 && (EARLY != 1 || mp < 2))
 #pragma unroll
-          for (int e = 0; e < (EARLY ? 2 : 1); ++e) {
+          for (int e = 0; e < (EARLY == 1 ? 2 : 1); ++e) {
             // the 8 pieces of this wave go out during the FIRST half of the K-step (2 per group of 16 MFMAs) so the
             // last one still has half a K-step of MFMAs to land behind  (EARLY: 4 per group, first quarter)
-            const int piece = wid * 4 + (EARLY ? mp * 2 + e : mp);
+            const int piece = wid * 4 + (EARLY == 1 ? mp * 2 + e : mp);
             int gr = i_m0 + piece * 8 + rin;
             gr = gr < g.M ? gr : g.M - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
@@ -502,11 +502,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.W + (size_t)gr * g.K + koff),
                                              (__attribute__((address_space(3))) void*)(nbuf + G3_BM * 128 + piece * 1024), 16, 0, 0);
           }
+          if (EARLY == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
             acc[ni][2 * mp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa0, acc[ni][2 * mp], 0, 0, 0);
             acc[ni][2 * mp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa1, acc[ni][2 * mp + 1], 0, 0, 0);
           }
+          if (EARLY == 2) __builtin_amdgcn_s_setprio(0);
           if (PF > 100 && more && kk == 0 && mp == 3 && wid == 1) {   // A/B probe: also prefetch the W slice (wave 1)
             int p_kt = i_kt + (PF - 100), p_n0 = i_n0;
             const bool pv = i_it + (PF - 100) < total_it;
@@ -669,6 +671,7 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   if (v == 6) return launch_gemm_p256<EPI, 1, 6>(g, st);     // default: interleaved DMA issue + L2 prefetch of A 6 K-steps ahead
   if (v == 65) return launch_gemm_p256<EPI, 1, 0>(g, st);    // A/B: no L2 prefetch
   if (v == 66) return launch_gemm_p256<EPI, 1, 6, 1>(g, st); // A/B: DMA pieces issued in the first quarter of the K-step
+  if (v == 67) return launch_gemm_p256<EPI, 1, 6, 2>(g, st); // A/B: s_setprio(1) around each group of 8 MFMAs
   if (v == 7) { g.P = -2; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 60) { g.P = -7; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 61) return launch_gemm_p256<EPI, 1, 3>(g, st);   // + L2 prefetch of A, 3 K-steps ahead
