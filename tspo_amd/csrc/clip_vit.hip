@@ -408,6 +408,65 @@ __device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int 
   }
 }
 
+// Epilogue of one 256x256 tile for a wave owning rows wm*128.. and columns wn*64.. (shared by the ring kernels).
+template <int EPI>
+__device__ __forceinline__ void g3_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
+                                            int l15, int q4, const float* lbias) {
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wm * 128 + mi * 16 + l15;
+    size_t orow = (size_t)m;
+    int prow = 0;
+    if (EPI == GE_PATCH) {
+      const int f = m / g.P;
+      prow = 1 + (m - f * g.P);
+      orow = (size_t)f * (g.P + 1) + prow;
+    }
+    uint2 pk[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + q4 * 4;
+      f32x4 v = acc[ni][mi];
+      acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const bool ok = m < g.M && n < g.N;
+      if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) v += *reinterpret_cast<const f32x4*>(lbias + (n < g.N ? n : 0));
+      if (EPI == GE_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+      }
+      const size_t o = orow * g.N + n;
+      if (EPI == GE_PATCH && ok) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
+      if (EPI == GE_RESID && ok) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(g.R + o);
+        v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+        v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+      }
+      if (EPI == GE_F32) {
+        if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
+      } else {
+        pk[ni].x = pack_bf16x2(v[0], v[1]);
+        pk[ni].y = pack_bf16x2(v[2], v[3]);
+      }
+    }
+    if (EPI != GE_F32) {
+      // widen the stores: v_permlane16_swap exchanges the odd 16-lane rows of tile a with the even rows of tile
+      // b, after which row q4 holds 16 contiguous bytes of tile (q4 & 1 ? b : a) at column (q4 >> 1) * 8
+      // -> 16 instead of 32 store instructions per wave and tile (the epilogue is store-issue bound)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const auto w0 = __builtin_amdgcn_permlane16_swap(pk[2 * pr].x, pk[2 * pr + 1].x, false, false);
+        const auto w1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr].y, pk[2 * pr + 1].y, false, false);
+        const int n = n0 + wn * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
+        if (m < g.M && n < g.N) {
+          uint4 st;
+          st.x = w0[0]; st.y = w1[0]; st.z = w0[1]; st.w = w1[1];
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + orow * g.N + n) = st;
+        }
+      }
+    }
+  }
+}
+
 template <int EPI, int MODE, int PF, int EARLY>
 __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int tilesM, int ngrp) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE + 16384 + 256];  // the ONLY LDS object (+256 B sink of the L2 prefetch)
@@ -418,6 +477,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
   if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID)
     for (int i = tid; i < g.N; i += 512) lbias[i] = g.bias[i];
   const int nk = g.K / GT_BK;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((size_t)g.M * g.K * 2), 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((size_t)g.N * g.K * 2), 0x00020000);
   const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
   const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
   const int panels = (tilesM - pset + npset - 1) / npset;
@@ -493,6 +554,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
             // the 8 pieces of this wave go out during the FIRST half of the K-step (2 per group of 16 MFMAs) so the
             // last one still has half a K-step of MFMAs to land behind  (EARLY: 4 per group, first quarter)
             const int piece = wid * 4 + (EARLY == 1 ? mp * 2 + e : mp);
+            if (EARLY == 3) {
+              // A/B: buffer_load ... lds through a resource descriptor (32-bit offsets, hardware range check instead
+              // of the row clamp)
+              const unsigned oa = ((unsigned)(i_m0 + piece * 8 + rin) * (unsigned)g.K + (unsigned)koff) * 2u;
+              const unsigned ow = ((unsigned)(i_n0 + piece * 8 + rin) * (unsigned)g.K + (unsigned)koff) * 2u;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(nbuf + piece * 1024), 16, oa, 0, 0, 0);
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(nbuf + G3_BM * 128 + piece * 1024), 16, ow, 0, 0, 0);
+            } else {
             int gr = i_m0 + piece * 8 + rin;
             gr = gr < g.M ? gr : g.M - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
@@ -501,6 +570,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
             gr = gr < g.N ? gr : g.N - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.W + (size_t)gr * g.K + koff),
                                              (__attribute__((address_space(3))) void*)(nbuf + G3_BM * 128 + piece * 1024), 16, 0, 0);
+            }
           }
           if (EARLY == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -584,59 +654,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
     }
     if (++c_kt == nk) {
       const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        const int m = m0 + wm * 128 + mi * 16 + l15;
-        size_t orow = (size_t)m;
-        int prow = 0;
-        if (EPI == GE_PATCH) {
-          const int f = m / g.P;
-          prow = 1 + (m - f * g.P);
-          orow = (size_t)f * (g.P + 1) + prow;
-        }
-        uint2 pk[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int n = n0 + wn * 64 + ni * 16 + q4 * 4;
-          f32x4 v = acc[ni][mi];
-          acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const bool ok = m < g.M && n < g.N;
-          if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) v += *reinterpret_cast<const f32x4*>(lbias + (n < g.N ? n : 0));
-          if (EPI == GE_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-          }
-          const size_t o = orow * g.N + n;
-          if (EPI == GE_PATCH && ok) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
-          if (EPI == GE_RESID && ok) {
-            const uint2 rv = *reinterpret_cast<const uint2*>(g.R + o);
-            v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
-            v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
-          }
-          if (EPI == GE_F32) {
-            if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
-          } else {
-            pk[ni].x = pack_bf16x2(v[0], v[1]);
-            pk[ni].y = pack_bf16x2(v[2], v[3]);
-          }
-        }
-        if (EPI != GE_F32) {
-          // widen the stores: v_permlane16_swap exchanges the odd 16-lane rows of tile a with the even rows of tile
-          // b, after which row q4 holds 16 contiguous bytes of tile (q4 & 1 ? b : a) at column (q4 >> 1) * 8
-          // -> 16 instead of 32 store instructions per wave and tile (the epilogue is store-issue bound)
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const auto w0 = __builtin_amdgcn_permlane16_swap(pk[2 * pr].x, pk[2 * pr + 1].x, false, false);
-            const auto w1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr].y, pk[2 * pr + 1].y, false, false);
-            const int n = n0 + wn * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
-            if (m < g.M && n < g.N) {
-              uint4 st;
-              st.x = w0[0]; st.y = w1[0]; st.z = w0[1]; st.w = w1[1];
-              *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + orow * g.N + n) = st;
-            }
-          }
-        }
-      }
+      g3_epilogue<EPI>(g, acc, m0, n0, wm, wn, l15, q4, lbias);
       c_kt = 0;
       c_s += nwl;
       after_epi = true;
@@ -659,6 +677,147 @@ int launch_gemm_p256(GemmArgs g, hipStream_t st) {
   return tspo::check_launch("gemm_bf16_p256");
 }
 
+
+// ===========================================================================
+// GEMM v4 ("role-split"): same 256x256x64 tile, ring, ownership and epilogue as v3, but the two wave-rows of the
+// workgroup run HALF A K-STEP OUT OF PHASE.  Waves w and w+4 share a SIMD; while one of them issues its 32 MFMAs
+// of a half K-step back to back (all fragments already in registers, s_setprio 1), the other one is in its LOAD
+// segment: 12 ds_read_b128 for its next half K-step plus its LDS-DMA pieces for the next stage.  So the matrix pipe
+// of a SIMD is fed by exactly one wave at a time and never waits behind LDS reads or DMA issue of that same wave.
+// Segments are separated by workgroup barriers (4 per K-step); group B (waves 4-7) takes one extra barrier up
+// front, group A one at the end.  Stage it+1 is issued by each wave in its LOAD segment of the first half of
+// K-step it - the first point at which every read of the buffer's previous contents is known to be complete - and
+// every wave drains its own DMA (vmcnt(0)) before the barrier that closes global segment 4*it+3.
+// ===========================================================================
+#define G4_BAR() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define G4_BAR_VM() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_s256_kernel(GemmArgs g, int tilesM, int ngrp) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE + 16384 + 256];  // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int wm = wid >> 2, wn = wid & 3;   // wm = wave-row = phase group (0: A leads, 1: B trails by one segment)
+  float* lbias = reinterpret_cast<float*>(lds + 2 * G3_STAGE);
+  if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID)
+    for (int i = tid; i < g.N; i += 512) lbias[i] = g.bias[i];
+  const int nk = g.K / GT_BK;
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
+  const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
+  const int panels = (tilesM - pset + npset - 1) / npset;
+  const int ntile_x = panels * n_per;
+  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
+  const int total_it = my_tiles * nk;
+  if (total_it == 0) return;
+
+  // issue-side cursor: stage index i_it of tile i_s, K-step i_kt
+  int i_it = 0, i_kt = 0, i_s = wl;
+  int i_m0 = ((i_s / n_per) * npset + pset) * G3_BM, i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
+  const int rin = lane >> 3, slot = lane & 7;
+  auto issue_stage = [&]() {   // this wave's 8 pieces (4 A + 4 W) of stage i_it, then advance the cursor
+    char* nbuf = lds + (i_it & 1) * G3_STAGE;
+    const size_t koff = (size_t)i_kt * GT_BK + ((slot ^ rin) << 3);
+#pragma unroll
+    for (int pce = 0; pce < 4; ++pce) {
+      const int piece = wid * 4 + pce;
+      int gr = i_m0 + piece * 8 + rin;
+      gr = gr < g.M ? gr : g.M - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
+                                       (__attribute__((address_space(3))) void*)(nbuf + piece * 1024), 16, 0, 0);
+      gr = i_n0 + piece * 8 + rin;
+      gr = gr < g.N ? gr : g.N - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.W + (size_t)gr * g.K + koff),
+                                       (__attribute__((address_space(3))) void*)(nbuf + G3_BM * 128 + piece * 1024), 16, 0, 0);
+    }
+    if (wid == 0) {  // L2 prefetch of the A slice 6 K-steps ahead (4-byte LDS-DMA per 128-B line into a sink)
+      int p_kt = i_kt + 6, p_m0 = i_m0;
+      if (p_kt >= nk) {
+        p_kt -= nk;
+        const int s2 = i_s + nwl;
+        p_m0 = ((s2 / n_per) * npset + pset) * G3_BM;
+      }
+      if (i_it + 6 < total_it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int gr = p_m0 + j * 64 + lane;
+          gr = gr < g.M ? gr : g.M - 1;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + (size_t)p_kt * GT_BK),
+              (__attribute__((address_space(3))) void*)(lds + 2 * G3_STAGE + 16384), 4, 0, 0);
+        }
+      }
+    }
+    ++i_it;
+    if (++i_kt == nk) {
+      i_kt = 0;
+      i_s += nwl;
+      i_m0 = ((i_s / n_per) * npset + pset) * G3_BM;
+      i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
+    }
+  };
+
+  int offA[8], offW[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) offA[i] = (wm * 128 + i * 16 + l15) * 128;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) offW[i] = G3_BM * 128 + (wn * 64 + i * 16 + l15) * 128;
+  const int sw = l15 & 7;
+
+  f32x4 acc[4][8];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: stage 0 everywhere, visible to all
+  issue_stage();
+  G4_BAR_VM();
+  if (wm == 1) G4_BAR();   // group B trails by one segment
+
+  int c_kt = 0, c_s = wl;
+  const int P = 2 * total_it;
+  for (int p = 0; p < P; ++p) {
+    const int it = p >> 1, kk = p & 1;
+    // ---------------- LOAD segment ----------------
+    const char* cur = lds + (it & 1) * G3_STAGE;
+    const int co = (((kk * 4 + q4) ^ sw) << 4);
+    bf16x8 fa[8], fw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(cur + offW[i] + co);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(cur + offA[i] + co);
+    if (kk == 0 && i_it < total_it) issue_stage();   // stage it+1 -> the buffer whose last readers finished a barrier ago
+    if (kk == 1 && wm == 1) G4_BAR_VM(); else G4_BAR();   // B closes global segment 4*it+3 here: its DMA must have landed
+    // ---------------- COMPUTE segment ----------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (kk == 1 && ++c_kt == nk) {
+      const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
+      g3_epilogue<EPI>(g, acc, m0, n0, wm, wn, l15, q4, lbias);
+      c_kt = 0;
+      c_s += nwl;
+    }
+    if (kk == 1 && wm == 0) G4_BAR_VM(); else G4_BAR();   // A closes global segment 4*it+3 here
+  }
+  if (wm == 0) G4_BAR();   // balance the barrier count of the two groups
+}
+
+template <int EPI>
+int launch_gemm_s256(GemmArgs g, hipStream_t st) {
+  const int tilesM = (g.M + G3_BM - 1) / G3_BM;
+  g.tilesN = (g.N + G3_BN - 1) / G3_BN;
+  g.nwg = tilesM * g.tilesN;
+  int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
+  if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
+  hipLaunchKernelGGL((gemm_bf16_s256_kernel<EPI>), dim3(256), dim3(512), 0, st, g, tilesM, ngrp);
+  return tspo::check_launch("gemm_bf16_s256");
+}
+
 // Variant choice: the persistent 256x256 kernel whenever there is at least one tile per CU; the small
 // 128x128 kernel otherwise.  Variants 2..29 are reachable only through tspo_gemm_bf16's test hook (act >> 8):
 // 2 = 256x128 ring, 3 = 2 without K-rotation, 4/5 = 2 compute-only / loads-only, 6 = 256x256, 7/8/9 = 6 compute-only /
@@ -672,6 +831,8 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   if (v == 65) return launch_gemm_p256<EPI, 1, 0>(g, st);    // A/B: no L2 prefetch
   if (v == 66) return launch_gemm_p256<EPI, 1, 6, 1>(g, st); // A/B: DMA pieces issued in the first quarter of the K-step
   if (v == 67) return launch_gemm_p256<EPI, 1, 6, 2>(g, st); // A/B: s_setprio(1) around each group of 8 MFMAs
+  if (v == 68) return launch_gemm_p256<EPI, 1, 6, 3>(g, st); // A/B: buffer_load ... lds instead of global_load_lds
+  if (v == 70) return launch_gemm_s256<EPI>(g, st);          // role-split (staggered wave rows)
   if (v == 7) { g.P = -2; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 60) { g.P = -7; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 61) return launch_gemm_p256<EPI, 1, 3>(g, st);   // + L2 prefetch of A, 3 K-steps ahead
