@@ -39,6 +39,12 @@ def _worker(rank, world, port, q):
     metrics = td.reduce_metrics(td.pack_metrics(
         dict(ts_length=16, completion_length=10 + rank, reward=0.5 * rank, advantages=0.0, reward_mean=rank, reward_std=1.0),
         [1.0 * rank, 0.25]), 2, ["accuracy_reward", "temporal_localization_reward"])
+    # frame-sharded apply + all-gather (uneven: 7 rows over 2 ranks) == applying fn to everything
+    x = torch.arange(7 * 3, dtype=torch.float32).view(7, 3)
+    y = td.sharded_apply(lambda t: t * 2 + 1, x)
+    assert torch.equal(y, x * 2 + 1), y
+    y1 = td.sharded_apply(lambda t: t.sum(dim=1, keepdim=True), x[:1])       # fewer rows than ranks
+    assert torch.equal(y1, x[:1].sum(dim=1, keepdim=True))
     q.put((rank, list(shard), bucket.numpy(), metrics))
     dist.barrier()
     dist.destroy_process_group()

@@ -63,3 +63,30 @@ def reduce_metrics(packed: torch.Tensor, n_reward_funcs: int, reward_names: Sequ
     for j, name in enumerate(reward_names[:n_reward_funcs]):
         out[f"rewards/{name}"] = t[len(METRIC_KEYS) + j].item()
     return out
+
+
+def shard_rows(n: int, world: int, rank: int) -> range:
+    """Contiguous shard of n rows (frames) for `rank`; shards differ by at most one row."""
+    return shard_prompts(n, world, rank)
+
+
+def sharded_apply(fn, x: torch.Tensor, group=None) -> torch.Tensor:
+    """Long-video option (SURVEY C3 / BASELINE configs[4]): when there are fewer videos than GPUs, shard the FRAMES of
+    one video across ranks for the encode and exchange the small result: every rank applies `fn` to its contiguous
+    slice of x along dim 0 and the per-rank outputs [n_r, D] are all-gathered into the full [n, D] on every rank
+    (one collective, 1.5 KB per frame).  fn must be row-wise independent (CLIP frame encode is)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return fn(x)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = x.shape[0]
+    mine = shard_rows(n, world, rank)
+    local = fn(x[mine.start:mine.stop]) if len(mine) else None
+    per = (n + world - 1) // world                       # pad every shard to the largest one
+    probe = local if local is not None else fn(x[:1])
+    buf = torch.zeros((per,) + tuple(probe.shape[1:]), dtype=probe.dtype, device=probe.device)
+    if local is not None:
+        buf[: local.shape[0]] = local
+    out = torch.empty((world * per,) + tuple(probe.shape[1:]), dtype=probe.dtype, device=probe.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    parts = [out[r * per: r * per + len(shard_rows(n, world, r))] for r in range(world)]
+    return torch.cat(parts, dim=0)

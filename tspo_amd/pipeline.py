@@ -27,8 +27,14 @@ class FrameScorer:
         self.dim, self.heads, self.window, self.tau = dim, heads, window_size, score_tau
         self._sel_ws = None
 
-    def encode(self, pixels: torch.Tensor) -> torch.Tensor:
-        """pixels [B,T,3,H,W] or [N,3,H,W] -> features f32 [.., proj]."""
+    def encode(self, pixels: torch.Tensor, shard_frames: bool = False, group=None) -> torch.Tensor:
+        """pixels [B,T,3,H,W] or [N,3,H,W] -> features f32 [.., proj].  shard_frames=True splits the frames of the
+        batch across the ranks of `group` and all-gathers the features (long-video option, tspo_amd.dist.sharded_apply)."""
+        if shard_frames:
+            from .dist import sharded_apply
+            flat = pixels.reshape(-1, *pixels.shape[-3:])
+            feats = sharded_apply(lambda px: ops.clip_vit_forward(self.clip, px), flat, group)
+            return feats.view(*pixels.shape[:-3], -1)
         if pixels.ndim == 5:
             B, T = pixels.shape[:2]
             return ops.clip_vit_forward(self.clip, pixels.reshape(B * T, *pixels.shape[2:])).view(B, T, -1)
