@@ -280,6 +280,50 @@ def test_gemm_bf16(M, N, K):
     np.testing.assert_allclose(out.numpy(), (ref + bias + R.float()).numpy(), **tol)
 
 
+@pytest.mark.parametrize("N,K", [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)], ids=["qkv", "out", "fc1", "fc2"])
+def test_gemm_bf16_persistent_kernel_full_check(N, K):
+    """The production (persistent 256x256 ring) kernel on the encoder's four GEMM shapes with a ragged M
+    (40 frames x 257 tokens = 10280 rows: 40 full row panels + one 40-row edge panel), EVERY output element
+    against a CPU fp32 reference, for each epilogue; plus every kept A/B variant that must stay correct."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    M = 257 * 40
+    A, W = _bf16r(synth.normal((M, K), 11 + N)), _bf16r(synth.normal((N, K), 12 + K, 0.03))
+    bias = T_(synth.normal((N,), 13, 0.1))
+    ref = A.float() @ W.float().t() + bias
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
+    tol = dict(rtol=1e-2, atol=2e-2)
+    if N == 4096:          # fc1: quick_gelu epilogue
+        want, kw = O.quick_gelu(ref), dict(act=1)
+    elif N == 1024:        # out-proj / fc2: residual epilogue
+        R = _bf16r(synth.normal((M, N), 14))
+        want, kw = ref + R.float(), dict(residual=R.to(DEV))
+    else:
+        want, kw = ref, {}
+    for variant in (0, 6, 2, 70):     # auto (= 6 here), explicit 256x256 ring, 256x128 ring, role-split
+        act = kw.get("act", 0) | (variant << 8)
+        out = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=act).float().cpu()
+        np.testing.assert_allclose(out.numpy(), want.numpy(), err_msg=f"variant {variant}", **tol)
+
+
+def test_clip_vit_forward_70_frames_production_kernels():
+    """70 frames (M = 17990 rows) is large enough that every encoder GEMM takes the persistent kernel: features vs
+    the fp32 oracle on the CPU (bf16-rounded matrices) within the encode tolerance."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    cfg, n = synth.CLIP_L14, 70
+    state = synth.clip_vision_state(**cfg)
+    w = {k: (T_(v).to(torch.bfloat16).float() if v.ndim >= 2 and "position_embedding" not in k else T_(v)) for k, v in state.items()}
+    u8 = synth.uniform_u8((n, 3, 224, 224), 4321)
+    with torch.no_grad():
+        ref = O.clip_vit_forward(w, O.clip_normalize_pixels(T_(u8)), num_heads=cfg["heads"], patch=cfg["patch"]).numpy()
+    W = ops.ClipVitWeights({k: T_(v) for k, v in state.items()}, cfg, DEV)
+    feat = ops.clip_vit_forward(W, G_(u8)).cpu().numpy()
+    scale = np.abs(ref).max()
+    err = np.abs(feat - ref).max() / scale
+    cos = (feat * ref).sum(-1) / np.linalg.norm(feat, axis=-1) / np.linalg.norm(ref, axis=-1)
+    print(f"\n[clip_l14 x70] max|err|/max|ref| {err:.4f}, min cos {cos.min():.6f}")
+    assert err < 3e-2 and cos.min() > 0.999
+
+
 def _clip_ref_bf16_weights(cfg, n):
     """fp32 oracle evaluated with bf16-rounded matrices (what the encoder stores), fp32 activations."""
     state = synth.clip_vision_state(**cfg)
