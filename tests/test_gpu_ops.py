@@ -105,6 +105,34 @@ def test_gumbel_topk_philox_and_batch():
         ops.gumbel_topk(G_(logits[:, :8]), 9, 1)
 
 
+def test_stress_config_T4096_G16():
+    """BASELINE configs[4] sizes on the policy side: T=4096 frames, G=16 rollouts, k=16 - selector scores vs the dense
+    CPU oracle, rollout indices bit-exact vs the oracle under the kernel's own Philox noise, PG gradient vs closed form."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    T, D, H, w, tau, G, k = 4096, 768, 8, 12, 0.025, 16, 16
+    img, txt = synth.normal((T, D), 4096), synth.normal((1, D), 4097)
+    state = synth.selector_state(D, seed=8, std=0.02, bias_std=0.01)
+    clip = O.clip_cosine_scores(T_(txt), T_(img)).numpy()
+    flat = flat_from_state(state, D)
+    s, _, ws = ops.selector_forward(flat, G_(img[None]), G_(txt[None]), G_(clip[None]), H, w, tau, want_attn=False)
+    s_ref, _ = O.selector_forward({n: T_(v) for n, v in state.items()}, T_(img), T_(txt), T_(clip), w, tau, H)
+    np.testing.assert_allclose(s[0].cpu().numpy(), s_ref.numpy(), rtol=2e-5, atol=2e-3)
+    out = ops.gumbel_topk(s, k, G, seed=7, offset=3, want_noise=True)
+    noise = out["noise"].cpu()
+    for g in range(G):
+        idx, _, _ = O.gumbel_topk(s[0].cpu(), noise[0, g], k)
+        np.testing.assert_array_equal(out["idx"][0, g].cpu().numpy(), idx.numpy())
+    rew = G_(((synth.uniform((G,), 5) > 0.5).astype(np.float32) + synth.uniform((G,), 6).astype(np.float32)).reshape(1, G))
+    adv = ops.grpo_advantage(rew)
+    dl, loss = ops.pg_grad_logits(out["logp"], out["idx"], adv)
+    l_ref, g_ref = O.pg_grad_logits(s[0].cpu(), out["idx"][0].cpu(), adv[0].cpu())
+    np.testing.assert_allclose(dl[0].cpu().numpy(), g_ref.numpy(), rtol=1e-4, atol=1e-7)
+    fg = torch.zeros_like(flat)
+    ops.selector_backward(flat, fg, G_(img[None]), G_(txt[None]), dl, H, w, tau, ws)
+    assert torch.isfinite(fg).all() and fg[: ops.trainable_numel(D)].abs().sum() > 0
+    assert ops.topk_sorted(s[0], 64).cpu().tolist() == O.topk_sorted(s[0].cpu(), 64).tolist()
+
+
 def test_advantage_and_pg_grad(golden):
     g = golden["train"]
     for nm in ("eq", "gen", "two", "bg"):
