@@ -1123,16 +1123,29 @@ __global__ __launch_bounds__(256, 2) void clip_attn_kernel(const bf16_t* __restr
   const size_t ld = (size_t)3 * C;
   const bf16_t* base = qkv + f * S * ld + (size_t)h * 64;
 
-  // ---- stage K (swizzled rows) and V (transposed) -------------------------
-  for (int id = tid; id < AT_KEYS * 8; id += 256) {
-    const int row = id >> 3, c = id & 7;
-    uint4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-    if (row < S) {
-      kv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + C + c * 8);
-      vv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + 2 * C + c * 8);
+  // ---- stage K (swizzled rows) and V (row-major sub-tiles) -------------------
+  // All 18 16-byte loads of a thread are issued before the first LDS write (rows past S are clamped and zeroed
+  // afterwards, so there is no branch around a load): the rolled, branchy version of this loop exposed one full
+  // memory latency per iteration - 9 round trips per workgroup.
+  {
+    uint4 kv[9], vv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int id = tid + i * 256;
+      const int row = id >> 3, c = id & 7;
+      const int rc = row < S ? row : S - 1;
+      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + C + c * 8);
+      vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + 2 * C + c * 8);
     }
-    *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kv;
-    *reinterpret_cast<uint4*>(Vt + ((row >> 5) * 4 + (c >> 1)) * 1024 + (row & 31) * 32 + (c & 1) * 16) = vv;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int id = tid + i * 256;
+      const int row = id >> 3, c = id & 7;
+      const uint4 z = {0u, 0u, 0u, 0u};
+      const uint4 k4 = row < S ? kv[i] : z, v4 = row < S ? vv[i] : z;
+      *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = k4;
+      *reinterpret_cast<uint4*>(Vt + ((row >> 5) * 4 + (c >> 1)) * 1024 + (row & 31) * 32 + (c & 1) * 16) = v4;
+    }
   }
   __syncthreads();
 
