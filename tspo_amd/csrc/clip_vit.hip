@@ -1026,16 +1026,25 @@ __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16
       qf[n][kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow[n] * ld + kk * 32 + q4 * 8);
   }
   f32x4 sc[NQ][18];
+  // K fragments are software-pipelined one key tile ahead (the MFMA of tile kt never waits on an LDS read issued
+  // just before it; before this the loop paid the LDS latency 36 times per pass)
+  const int nkt = (S + 15) >> 4;   // key tiles that hold at least one valid key (17 for S = 257)
+  bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(Ks + koff + ((q4 ^ ksw) << 4));
+  bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(Ks + koff + (((4 + q4) ^ ksw) << 4));
 #pragma unroll
   for (int kt = 0; kt < 18; ++kt) {
 #pragma unroll
     for (int n = 0; n < NQ; ++n) sc[n][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (kt * 16 < S) {  // key tiles entirely past the sequence are never multiplied (uniform branch)
+    bf16x8 nf0 = kf0, nf1 = kf1;
+    if (kt + 1 < 18) {   // rows past S are zero-filled in LDS, so the read itself is always safe
+      nf0 = *reinterpret_cast<const bf16x8*>(Ks + (kt + 1) * 2048 + koff + ((q4 ^ ksw) << 4));
+      nf1 = *reinterpret_cast<const bf16x8*>(Ks + (kt + 1) * 2048 + koff + (((4 + q4) ^ ksw) << 4));
+    }
+    if (kt < nkt) {  // key tiles entirely past the sequence are never multiplied (uniform branch)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + koff + (((kk * 4 + q4) ^ ksw) << 4));
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) sc[n][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[n][kk], sc[n][kt], 0, 0, 0);
+      for (int n = 0; n < NQ; ++n) {
+        sc[n][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[n][0], sc[n][kt], 0, 0, 0);
+        sc[n][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[n][1], sc[n][kt], 0, 0, 0);
       }
     }
     if ((kt + 1) * 16 > S) {  // only the tile(s) straddling / past S need the key mask
@@ -1044,6 +1053,8 @@ __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[n][kt][r] = (kt * 16 + q4 * 4 + r) < S ? sc[n][kt][r] : -INFINITY;
     }
+    kf0 = nf0;
+    kf1 = nf1;
   }
   // softmax over keys: lane holds keys kt*16 + q4*4 + r for query l15
   const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = 2^(x*scale*log2 e): one v_fma + one v_exp per score
@@ -1076,6 +1087,15 @@ __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16
   for (int n = 0; n < NQ; ++n)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[n][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  union VF { bf16x8 v; s16x4 h2[2]; };
+  auto ldv = [&](int step) {   // step = c * 4 + dt
+    VF f;
+    const int c = step >> 2, dt = step & 3;
+    f.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vt + voff[dt][0] + c * 4096));
+    f.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vt + voff[dt][1] + c * 4096));
+    return f;
+  };
+  VF vcur = ldv(0);
 #pragma unroll
   for (int c = 0; c < 9; ++c) {
     union { bf16x8 v; uint32_t u[4]; } pf[NQ];
@@ -1088,11 +1108,12 @@ __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      union { bf16x8 v; s16x4 h2[2]; } vf;
-      vf.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vt + voff[dt][0] + c * 4096));
-      vf.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vt + voff[dt][1] + c * 4096));
+      const int step = c * 4 + dt;
+      VF vnext = vcur;
+      if (step + 1 < 36) vnext = ldv(step + 1);
 #pragma unroll
-      for (int n = 0; n < NQ; ++n) o[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[n].v, o[n][dt], 0, 0, 0);
+      for (int n = 0; n < NQ; ++n) o[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcur.v, pf[n].v, o[n][dt], 0, 0, 0);
+      vcur = vnext;
     }
   }
 #pragma unroll
