@@ -999,10 +999,11 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // NQ query tiles (16 queries each, tiles qt and qt+qstride) against all keys of one (frame, head).
-template <int NQ>
+template <int NQ, int S_CT>
 __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16_t* __restrict__ out, const char* Ks,
-                                           const char* Vt, int S, int C, size_t ld, size_t f, int h, float scale, int qt0,
+                                           const char* Vt, int S_rt, int C, size_t ld, size_t f, int h, float scale, int qt0,
                                            int qstride, int l15, int q4) {
+  const int S = S_CT ? S_CT : S_rt;   // S_CT = 257 (ViT-L/14 @ 224): every tile-skip / mask decision folds at compile time
   // V^T fragments come from ds_read_b64_tr_b16: the 16 lanes of a row each point at 4 contiguous bf16 of a
   // row-major [4 keys][16 d] block (lane i -> key i>>2, d-chunk i&3) and receive COLUMN i of it, i.e. 4 keys of
   // their own d - so V stays row-major in LDS (16-byte staging writes, no scattered 2-byte transposition).
@@ -1095,6 +1096,7 @@ __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16
     f.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vt + voff[dt][1] + c * 4096));
     return f;
   };
+  constexpr bool VPF = true;   // (A/B: without the V prefetch the paired path measured 18.0 ms vs 15.6 ms per video)
   VF vcur = ldv(0);
 #pragma unroll
   for (int c = 0; c < 9; ++c) {
@@ -1110,7 +1112,8 @@ __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16
     for (int dt = 0; dt < 4; ++dt) {
       const int step = c * 4 + dt;
       VF vnext = vcur;
-      if (step + 1 < 36) vnext = ldv(step + 1);
+      if (VPF && step + 1 < 36) vnext = ldv(step + 1);
+      if (!VPF) vcur = ldv(step);
 #pragma unroll
       for (int n = 0; n < NQ; ++n) o[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcur.v, pf[n].v, o[n][dt], 0, 0, 0);
       vcur = vnext;
@@ -1132,8 +1135,10 @@ __device__ __forceinline__ void attn_tiles(const bf16_t* __restrict__ base, bf16
 }
 
 
-__global__ __launch_bounds__(256, 2) void clip_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
+template <int S_CT>
+__global__ __launch_bounds__(256, 2) void clip_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S_rt,
                                                         int C, float scale) {
+  const int S = S_CT ? S_CT : S_rt;
   __shared__ __attribute__((aligned(16))) char lds[AT_LDS_BYTES];
   char* Ks = lds;
   char* Vt = lds + AT_KEYS * 128;
@@ -1178,10 +1183,10 @@ __global__ __launch_bounds__(256, 2) void clip_attn_kernel(const bf16_t* __restr
   while (qt < nqt) {
     asm volatile("" ::: "memory");  // keep the loop-invariant K / Vt fragment reads inside the loop (register budget)
     if (qt + 4 < nqt) {
-      attn_tiles<2>(base, out, Ks, Vt, S, C, ld, f, h, scale, qt, 4, l15, q4);
+      attn_tiles<2, S_CT>(base, out, Ks, Vt, S, C, ld, f, h, scale, qt, 4, l15, q4);
       qt += 8;
     } else {
-      attn_tiles<1>(base, out, Ks, Vt, S, C, ld, f, h, scale, qt, 4, l15, q4);
+      attn_tiles<1, S_CT>(base, out, Ks, Vt, S, C, ld, f, h, scale, qt, 4, l15, q4);
       qt += 4;
     }
   }
@@ -1351,7 +1356,8 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
     g.A = b.h; g.W = (const bf16_t*)L.wqkv; g.bias = L.bqkv; g.C = b.qkv; g.M = (int)M; g.N = 3 * C; g.K = C; g.P = 1;
     if (int e = launch_gemm<GE_BIAS>(g, st)) return e;
     prof.tick(PK_GEMM);
-    hipLaunchKernelGGL(clip_attn_kernel, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
+    if (S == 257) hipLaunchKernelGGL(clip_attn_kernel<257>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
+    else hipLaunchKernelGGL(clip_attn_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     if (int e = tspo::check_launch("clip_attn")) return e;
     prof.tick(PK_ATTN);
     g = GemmArgs{};
