@@ -504,15 +504,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
     for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int c_kt = 0, c_s = wl;
+  unsigned long long dbg_vm = 0, dbg_bar = 0;
+  const unsigned long long dbg_t0 = EARLY == 4 ? __builtin_readcyclecounter() : 0;
   bool after_epi = true;   // first wait: nothing but the first stage is outstanding
   for (int it = 0; it < total_it; ++it) {
     // stage `it` landed everywhere; buffer (it+1)&1 is free.  Wave 0 may leave its 4 (younger) L2-prefetch ops in flight,
     // except right after an epilogue whose stores are younger still.
+    unsigned long long tw0 = 0;
+    if (EARLY == 4) tw0 = __builtin_readcyclecounter();
     if (PF > 0 && (wid == 0 || (PF > 100 && wid == 1)) && !after_epi) {
-      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      if (EARLY == 4) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_vm += t1 - tw0; tw0 = t1; }
+      asm volatile("s_barrier" ::: "memory");
     } else if (g.P != -7) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (EARLY == 4) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_vm += t1 - tw0; tw0 = t1; }
+      asm volatile("s_barrier" ::: "memory");
     }
+    if (EARLY == 4) dbg_bar += __builtin_readcyclecounter() - tw0;
     after_epi = false;
     const char* cur = lds + (it & 1) * G3_STAGE;
     if (MODE == 1) {
@@ -644,6 +653,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
       c_s += nwl;
       after_epi = true;
     }
+  }
+  if (EARLY == 4 && lane == 0 && g.pos) {   // timing probe: per wave {cycles in vmcnt wait, cycles in barrier, total, K-steps}
+    float* d = const_cast<float*>(g.pos) + (blockIdx.x * 8 + wid) * 4;
+    d[0] = (float)dbg_vm; d[1] = (float)dbg_bar; d[2] = (float)(__builtin_readcyclecounter() - dbg_t0); d[3] = (float)total_it;
   }
 }
 
@@ -817,6 +830,7 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   if (v == 66) return launch_gemm_p256<EPI, 1, 6, 1>(g, st); // A/B: DMA pieces issued in the first quarter of the K-step
   if (v == 67) return launch_gemm_p256<EPI, 1, 6, 2>(g, st); // A/B: s_setprio(1) around each group of 8 MFMAs
   if (v == 68) return launch_gemm_p256<EPI, 1, 6, 3>(g, st); // A/B: buffer_load ... lds instead of global_load_lds
+  if (v == 69) return launch_gemm_p256<EPI, 1, 6, 4>(g, st); // timing probe (s_memtime around the per-K-step wait); g.pos = debug buffer
   if (v == 70) return launch_gemm_s256<EPI>(g, st);          // role-split (staggered wave rows)
   if (v == 7) { g.P = -2; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 60) { g.P = -7; return launch_gemm_p256<EPI, 1>(g, st); }
