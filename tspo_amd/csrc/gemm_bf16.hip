@@ -394,12 +394,12 @@ __device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int 
 }
 
 // Epilogue of one 256x256 tile for a wave owning rows wm*128.. and columns wn*64.. (shared by the ring kernels).
-template <int EPI>
-__device__ __forceinline__ void g3_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
-                                            int l15, int q4, const float* lbias) {
+template <int EPI, int MI>
+__device__ __forceinline__ void g3_epilogue_t(const GemmArgs& g, f32x4 (&acc)[4][MI], int m0, int n0, int rbase, int wn,
+                                              int l15, int q4, const float* lbias) {
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int m = m0 + wm * 128 + mi * 16 + l15;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + rbase + mi * 16 + l15;
     size_t orow = (size_t)m;
     int prow = 0;
     if (EPI == GE_PATCH) {
@@ -450,6 +450,12 @@ __device__ __forceinline__ void g3_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8
       }
     }
   }
+}
+
+template <int EPI>
+__device__ __forceinline__ void g3_epilogue(const GemmArgs& g, f32x4 (&acc)[4][8], int m0, int n0, int wm, int wn,
+                                            int l15, int q4, const float* lbias) {
+  g3_epilogue_t<EPI, 8>(g, acc, m0, n0, wm * 128, wn, l15, q4, lbias);
 }
 
 template <int EPI, int MODE, int PF, int EARLY>
@@ -816,6 +822,120 @@ int launch_gemm_s256(GemmArgs g, hipStream_t st) {
   return tspo::check_launch("gemm_bf16_s256");
 }
 
+
+// ===========================================================================
+// GEMM v5: the same persistent 256x256x64 tile / 2-stage ring, but 16 waves per workgroup (4x4, 64x64 each = 4x4
+// MFMA tiles, 64 accumulators) = FOUR waves per SIMD.  Motivation (s_memtime probe on v3, tools/probe_gemm_wait.py):
+// per K-step of ~3650 cycles only ~80 are spent waiting for the LDS-DMA (the data has landed), but ~760 at the
+// barrier because the older of the two waves of a SIMD races ahead and then idles while the younger one cannot keep
+// the matrix pipe busy on its own.  With four lighter waves per SIMD some wave is always ready to issue MFMAs.
+// ===========================================================================
+template <int EPI>
+__global__ __launch_bounds__(1024) void gemm_bf16_w16_kernel(GemmArgs g, int tilesM, int ngrp) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE + 16384 + 256];  // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int wm = wid >> 2, wn = wid & 3;
+  float* lbias = reinterpret_cast<float*>(lds + 2 * G3_STAGE);
+  if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID)
+    for (int i = tid; i < g.N; i += 1024) lbias[i] = g.bias[i];
+  const int nk = g.K / GT_BK;
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
+  const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
+  const int panels = (tilesM - pset + npset - 1) / npset;
+  const int ntile_x = panels * n_per;
+  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
+  const int total_it = my_tiles * nk;
+  if (total_it == 0) return;
+
+  int i_it = 0, i_kt = 0, i_s = wl;
+  int i_m0 = ((i_s / n_per) * npset + pset) * G3_BM, i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
+  const int rin = lane >> 3, slot = lane & 7;
+  auto advance = [&]() {
+    ++i_it;
+    if (++i_kt == nk) {
+      i_kt = 0;
+      i_s += nwl;
+      i_m0 = ((i_s / n_per) * npset + pset) * G3_BM;
+      i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
+    }
+  };
+  auto issue_piece = [&](int q) {   // q = 0..3: pieces 2*wid, 2*wid+1 of A then of W, for stage i_it
+    char* nbuf = lds + (i_it & 1) * G3_STAGE;
+    const size_t koff = (size_t)i_kt * GT_BK + ((slot ^ rin) << 3);
+    const int piece = wid * 2 + (q & 1);
+    if (q < 2) {
+      int gr = i_m0 + piece * 8 + rin;
+      gr = gr < g.M ? gr : g.M - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
+                                       (__attribute__((address_space(3))) void*)(nbuf + piece * 1024), 16, 0, 0);
+    } else {
+      int gr = i_n0 + piece * 8 + rin;
+      gr = gr < g.N ? gr : g.N - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.W + (size_t)gr * g.K + koff),
+                                       (__attribute__((address_space(3))) void*)(nbuf + G3_BM * 128 + piece * 1024), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_piece(q);
+  advance();
+
+  int offA[4], offW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    offA[i] = (wm * 64 + i * 16 + l15) * 128;
+    offW[i] = G3_BM * 128 + (wn * 64 + i * 16 + l15) * 128;
+  }
+  const int sw = l15 & 7;
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int c_kt = 0, c_s = wl;
+  for (int it = 0; it < total_it; ++it) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const char* cur = lds + (it & 1) * G3_STAGE;
+    const bool more = i_it < total_it;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int co = (((kk * 4 + q4) ^ sw) << 4);
+      bf16x8 fa[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fw[i] = *reinterpret_cast<const bf16x8*>(cur + offW[i] + co);
+        fa[i] = *reinterpret_cast<const bf16x8*>(cur + offA[i] + co);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        if (more && kk == 0) issue_piece(mi);   // one piece behind each group of 4 MFMAs of the first half K-step
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+      }
+    }
+    if (more) advance();
+    if (++c_kt == nk) {
+      const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
+      g3_epilogue_t<EPI, 4>(g, acc, m0, n0, wm * 64, wn, l15, q4, lbias);
+      c_kt = 0;
+      c_s += nwl;
+    }
+  }
+}
+
+template <int EPI>
+int launch_gemm_w16(GemmArgs g, hipStream_t st) {
+  const int tilesM = (g.M + G3_BM - 1) / G3_BM;
+  g.tilesN = (g.N + G3_BN - 1) / G3_BN;
+  g.nwg = tilesM * g.tilesN;
+  int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
+  if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
+  hipLaunchKernelGGL((gemm_bf16_w16_kernel<EPI>), dim3(256), dim3(1024), 0, st, g, tilesM, ngrp);
+  return tspo::check_launch("gemm_bf16_w16");
+}
+
 // Variant choice: the persistent 256x256 kernel whenever there is at least one tile per CU; the small
 // 128x128 kernel otherwise.  Variants 2..29 are reachable only through tspo_gemm_bf16's test hook (act >> 8):
 // 2 = 256x128 ring, 3 = 2 without K-rotation, 4/5 = 2 compute-only / loads-only, 6 = 256x256, 7/8/9 = 6 compute-only /
@@ -832,6 +952,7 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   if (v == 68) return launch_gemm_p256<EPI, 1, 6, 3>(g, st); // A/B: buffer_load ... lds instead of global_load_lds
   if (v == 69) return launch_gemm_p256<EPI, 1, 6, 4>(g, st); // timing probe (s_memtime around the per-K-step wait); g.pos = debug buffer
   if (v == 70) return launch_gemm_s256<EPI>(g, st);          // role-split (staggered wave rows)
+  if (v == 71) return launch_gemm_w16<EPI>(g, st);           // 16 waves per workgroup (4 per SIMD)
   if (v == 7) { g.P = -2; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 60) { g.P = -7; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 61) return launch_gemm_p256<EPI, 1, 3>(g, st);   // + L2 prefetch of A, 3 K-steps ahead
