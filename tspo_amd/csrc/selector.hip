@@ -116,11 +116,97 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
     }
 }
 
+// LDS-staged version of the same GEMM (used when K % 32 == 0): the fragment-shaped global loads of the kernel above
+// (16 rows x 64 B per wave instruction) are address-processing bound; here each 64x32-float operand tile is brought in
+// as full 128-byte rows by LDS-DMA (XOR-swizzled like the bf16 GEMM tiles) and fragments come from ds_read_b128.
+// 64x64 outputs per workgroup, 4 waves (2x2) of 32x32, BK = 32, two stages (32 KB of LDS -> 5 workgroups per CU).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, const float* __restrict__ R,
+                                                              float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 16384];   // 2 stages x (A 64x128 B | W 64x128 B); the only LDS object
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int nk = K >> 5;
+  const int rin = lane >> 3, slot = lane & 7;
+  auto stage = [&](int kt, char* buf) {   // 16 pieces of 1 KB (8 rows x 128 B); wave wid: A pieces 2*wid, 2*wid+1 and the same of W
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int piece = wid * 2 + p;
+      const int r = piece * 8 + rin;
+      int gr = m0 + r;
+      gr = gr < M ? gr : M - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)gr * K + kt * 32 + ((slot ^ rin) << 2)),
+                                       (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (size_t)(n0 + r) * K + kt * 32 + ((slot ^ rin) << 2)),
+                                       (__attribute__((address_space(3))) void*)(buf + 8192 + piece * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offA[2], offW[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    offA[i] = (wm * 32 + i * 16 + l15) * 128;
+    offW[i] = 8192 + (wn * 32 + i * 16 + l15) * 128;
+  }
+  const int sw = l15 & 7;
+  stage(0, lds);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();   // stage kt landed (vmcnt(0) folded in by the compiler), compute(kt-1) done everywhere
+    const char* cur = lds + (kt & 1) * 16384;
+    if (kt + 1 < nk) stage(kt + 1, lds + ((kt + 1) & 1) * 16384);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int co = (((kk * 4 + q) ^ sw) << 4);
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const f32x4*>(cur + offA[i] + co);
+        b[i] = *reinterpret_cast<const f32x4*>(cur + offW[i] + co);
+      }
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][st], b[j][st], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 32 + 16 * j + l15;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + 16 * i + q * 4 + r;
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          const size_t o = (size_t)row * N + col;
+          if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+          if (EPI == EPI_RESID) v += R[o];
+          if (EPI == EPI_MASK) v = R[o] > 0.f ? v : 0.f;
+          C[o] = v;
+        }
+      }
+    }
+}
+
 template <int EPI>
 int launch_gemm_nt(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
                    hipStream_t st) {
   dim3 grid(N / 64, (M + 63) / 64);
-  hipLaunchKernelGGL((gemm_f32_nt_kernel<EPI>), grid, dim3(256), 0, st, A, W, bias, R, C, M, N, K);
+  if (K % 32 == 0)
+    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI>), grid, dim3(256), 0, st, A, W, bias, R, C, M, N, K);
+  else
+    hipLaunchKernelGGL((gemm_f32_nt_kernel<EPI>), grid, dim3(256), 0, st, A, W, bias, R, C, M, N, K);
   return tspo::check_launch("selector gemm_nt");
 }
 
