@@ -89,16 +89,30 @@ __device__ void select_topk_sorted(const uint32_t* __restrict__ keys, int T, int
       if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t cum = 0;
-      int b = 255;
-      for (; b > 0; --b) {
-        const uint32_t h = sh.hist[b];
-        if (cum + h >= need) break;
-        cum += h;
+    if (tid < 64) {
+      // wave 0 walks the histogram from the top: lane l owns bins 4l..4l+3; a suffix scan over the lanes finds the
+      // one lane whose bins contain the need-th largest candidate, which then resolves the bin serially (4 steps).
+      const uint32_t h0 = sh.hist[4 * tid], h1 = sh.hist[4 * tid + 1], h2 = sh.hist[4 * tid + 2], h3 = sh.hist[4 * tid + 3];
+      const uint32_t tot = h0 + h1 + h2 + h3;
+      uint32_t suf = tot;   // inclusive suffix sum over lanes >= tid
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_down(suf, o, 64);
+        if (tid + o < 64) suf += v;
       }
-      sh.prefix = prefix | ((uint32_t)b << shift);
-      sh.need = need - cum;
+      uint32_t cum = suf - tot;   // candidates in bins above this lane's
+      const bool mine = cum < need && need <= suf;
+      // fewer candidates than needed cannot happen (k <= T); lane 0 is the fallback like the serial walk's b = 0
+      const bool fallback = tid == 0 && need > suf;
+      if (mine || fallback) {
+        int b = 4 * tid;
+        if (cum + h3 >= need) b += 3;
+        else if (cum + h3 + h2 >= need) { b += 2; cum += h3; }
+        else if (cum + h3 + h2 + h1 >= need) { b += 1; cum += h3 + h2; }
+        else cum += h3 + h2 + h1;
+        sh.prefix = prefix | ((uint32_t)b << shift);
+        sh.need = need - cum;
+      }
     }
     __syncthreads();
     prefix = sh.prefix;

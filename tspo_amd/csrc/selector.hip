@@ -117,76 +117,111 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 }
 
 // LDS-staged version of the same GEMM (used when K % 32 == 0): the fragment-shaped global loads of the kernel above
-// (16 rows x 64 B per wave instruction) are address-processing bound; here each 64x32-float operand tile is brought in
-// as full 128-byte rows by LDS-DMA (XOR-swizzled like the bf16 GEMM tiles) and fragments come from ds_read_b128.
-// 64x64 outputs per workgroup, 4 waves (2x2) of 32x32, BK = 32, two stages (32 KB of LDS -> 5 workgroups per CU).
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                              const float* __restrict__ bias, const float* __restrict__ R,
-                                                              float* __restrict__ C, int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 16384];   // 2 stages x (A 64x128 B | W 64x128 B); the only LDS object
+// (16 rows x 64 B per wave instruction) are address-processing bound; here each 32-float-deep operand slab is brought
+// in as full 128-byte rows by LDS-DMA (XOR-swizzled like the bf16 GEMM tiles) and fragments come from ds_read_b128.
+// One workgroup = 64 x (32*WN) outputs, NWM x 2 waves of (64/NWM) x (16*WN); 3-deep ring with counted vmcnt waits.
+// WN = 3 (64x96 tiles) is used when N % 96 == 0: for D = 768 that makes BT=2048 x 768 exactly 256 workgroups (one
+// per CU) and x 2304 exactly 3 per CU, instead of 1.5 / 4.5 with 64x64 tiles, and gives 48 MFMAs per barrier.
+#define NT_NST 3
+template <int EPI, int WN, int NWM>
+__global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ R, float* __restrict__ C,
+                                                                    int M, int N, int K) {
+  constexpr int NW = NWM * 2;                  // waves: NWM along M x 2 along N
+  constexpr int MI = 4 / NWM;                  // 16-row tiles per wave (64 rows / NWM / 16)
+  constexpr int BN = 32 * WN;                  // W rows per slab
+  constexpr int PIECES = 8 + BN / 8;           // 1 KB DMA pieces per slab (A: 8, W: BN/8)
+  constexpr int PW_HI = (PIECES + NW - 1) / NW, PW_LO = PIECES / NW;   // first NHI waves move PW_HI pieces, the rest PW_LO
+  constexpr int NHI = PIECES - PW_LO * NW;     // (0 when it divides evenly)
+  constexpr int SLAB = PIECES * 1024;
+  __shared__ __attribute__((aligned(16))) char lds[NT_NST * SLAB];   // ring of (A 64x128 B | W BNx128 B); the only LDS object
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, q = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
   const int nk = K >> 5;
   const int rin = lane >> 3, slot = lane & 7;
-  auto stage = [&](int kt, char* buf) {   // 16 pieces of 1 KB (8 rows x 128 B); wave wid: A pieces 2*wid, 2*wid+1 and the same of W
+  const bool hi = NHI == 0 || wid < NHI;
+  const int piece0 = hi ? wid * PW_HI : NHI * PW_HI + (wid - NHI) * PW_LO;
+  auto stage = [&](int kt, int ring) {
+    char* buf = lds + ring * SLAB;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int piece = wid * 2 + p;
-      const int r = piece * 8 + rin;
-      int gr = m0 + r;
-      gr = gr < M ? gr : M - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)gr * K + kt * 32 + ((slot ^ rin) << 2)),
-                                       (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (size_t)(n0 + r) * K + kt * 32 + ((slot ^ rin) << 2)),
-                                       (__attribute__((address_space(3))) void*)(buf + 8192 + piece * 1024), 16, 0, 0);
+    for (int p = 0; p < PW_HI; ++p) {
+      if (p < PW_LO || hi) {
+        const int piece = piece0 + p;            // wave-uniform
+        const float* src;
+        if (piece < 8) {
+          int gr = m0 + piece * 8 + rin;
+          gr = gr < M ? gr : M - 1;
+          src = A + (size_t)gr * K;
+        } else {
+          src = W + (size_t)(n0 + (piece - 8) * 8 + rin) * K;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + kt * 32 + ((slot ^ rin) << 2)),
+                                         (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+      }
     }
   };
-  f32x4 acc[2][2];
+  auto wait_one_ahead = [&]() {   // all but the newest slab's DMA instructions of this wave have landed
+    if (hi) {
+      if (PW_HI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (PW_HI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (PW_HI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      if (PW_LO == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (PW_LO == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+  };
+  static_assert(PW_HI >= 2 && PW_HI <= 5 && PW_LO >= 2, "unexpected DMA piece split");
+  f32x4 acc[MI][WN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int offA[2], offW[2];
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offA[MI], offW[WN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    offA[i] = (wm * 32 + i * 16 + l15) * 128;
-    offW[i] = 8192 + (wn * 32 + i * 16 + l15) * 128;
-  }
+  for (int i = 0; i < MI; ++i) offA[i] = (wm * 16 * MI + i * 16 + l15) * 128;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) offW[j] = 8192 + (wn * 16 * WN + j * 16 + l15) * 128;
   const int sw = l15 & 7;
-  stage(0, lds);
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  int ring = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();   // stage kt landed (vmcnt(0) folded in by the compiler), compute(kt-1) done everywhere
-    const char* cur = lds + (kt & 1) * 16384;
-    if (kt + 1 < nk) stage(kt + 1, lds + ((kt + 1) & 1) * 16384);
+    if (kt + 1 < nk) wait_one_ahead();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // slab kt visible to all waves; compute(kt-1) done everywhere -> its slot is free
+    if (kt + 2 < nk) stage(kt + 2, ring >= 1 ? ring - 1 : NT_NST - 1);
+    const char* cur = lds + ring * SLAB;
+    ring = ring + 1 == NT_NST ? 0 : ring + 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int co = (((kk * 4 + q) ^ sw) << 4);
-      f32x4 a[2], b[2];
+      f32x4 a[MI], b[WN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const f32x4*>(cur + offA[i] + co);
-        b[i] = *reinterpret_cast<const f32x4*>(cur + offW[i] + co);
-      }
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(cur + offA[i] + co);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = *reinterpret_cast<const f32x4*>(cur + offW[j] + co);
 #pragma unroll
       for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][st], b[j][st], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][st], b[j][st], acc[i][j], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 32 + 16 * j + l15;
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + wn * 16 * WN + 16 * j + l15;
       const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 32 + 16 * i + q * 4 + r;
+        const int row = m0 + wm * 16 * MI + 16 * i + q * 4 + r;
         if (row < M) {
           float v = acc[i][j][r] + bv;
           const size_t o = (size_t)row * N + col;
@@ -202,11 +237,13 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_lds_kernel(const float* __res
 template <int EPI>
 int launch_gemm_nt(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
                    hipStream_t st) {
-  dim3 grid(N / 64, (M + 63) / 64);
-  if (K % 32 == 0)
-    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI>), grid, dim3(256), 0, st, A, W, bias, R, C, M, N, K);
+  const int mt = (M + 63) / 64;
+  if (K % 32 == 0 && N % 96 == 0)
+    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
+  else if (K % 32 == 0)
+    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 2, 4>), dim3(N / 64, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
   else
-    hipLaunchKernelGGL((gemm_f32_nt_kernel<EPI>), grid, dim3(256), 0, st, A, W, bias, R, C, M, N, K);
+    hipLaunchKernelGGL((gemm_f32_nt_kernel<EPI>), dim3(N / 64, mt), dim3(256), 0, st, A, W, bias, R, C, M, N, K);
   return tspo::check_launch("selector gemm_nt");
 }
 
@@ -518,34 +555,132 @@ __global__ __launch_bounds__(256) void gemm_f32_tn_kernel(const float* __restric
     }
 }
 
-// out[i] = sum_s part[s][i]   (fixed order -> deterministic)
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                           size_t n, int S) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+// LDS-staged version of the weight-gradient GEMM (NI, NJ multiples of 128): one workgroup = 128x128 outputs (4 waves of
+// 64x64 as above); operand slabs of 16 contraction rows (2 x 8 KB) travel by LDS-DMA through a 4-deep ring with counted
+// vmcnt waits, so ~3 slabs of loads are in flight per workgroup — the direct-load kernel above keeps a single wave per
+// SIMD waiting on HBM/L2 latency.  Fragment reads are conflict-free ds_read_b128 (16 lanes = 256 contiguous bytes).
+#define TN_ROWS 16
+#define TN_NST 4
+__global__ __launch_bounds__(256, 2) void gemm_f32_tn_lds_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                                 float* __restrict__ Cp, int Mrows, int NI, int NJ,
+                                                                 int chunk) {
+  __shared__ __attribute__((aligned(16))) char lds[TN_NST * 16384];   // per stage: A 16x512 B | B 16x512 B
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wi = wid >> 1, wj = wid & 1;
+  const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+  const int s = blockIdx.z;
+  const int mb = s * chunk, me = min(Mrows, mb + chunk);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nst = me > mb ? (me - mb + TN_ROWS - 1) / TN_ROWS : 0;
+  const int rlast = me > mb ? me - 1 : mb;
+  const int prow = lane >> 5, pcol = (lane & 31) << 2;
+  auto stage = [&](int t) {   // wave wid moves rows 4*wid..4*wid+3 of both slabs (2 rows per DMA instruction)
+    char* buf = lds + (t & (TN_NST - 1)) * 16384;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int rr = wid * 4 + p * 2 + prow;
+      int r = mb + t * TN_ROWS + rr;
+      r = r < rlast ? r : rlast;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + (size_t)r * NI + i0 + pcol),
+                                       (__attribute__((address_space(3))) void*)(buf + (wid * 4 + p * 2) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)r * NJ + j0 + pcol),
+                                       (__attribute__((address_space(3))) void*)(buf + 8192 + (wid * 4 + p * 2) * 512), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < TN_NST - 1; ++t)
+    if (t < nst) stage(t);
+  const int offA = (wi * 64 + 4 * l15) * 4, offB = 8192 + (wj * 64 + 4 * l15) * 4;
+  for (int t = 0; t < nst; ++t) {
+    // slabs t+1, t+2 (4 DMA instructions each per wave) may stay in flight
+    const int ahead = min(TN_NST - 2, nst - 1 - t);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // slab t visible to all waves; everyone is done with slab t-1 -> its slot is free
+    if (t + TN_NST - 1 < nst) stage(t + TN_NST - 1);
+    const char* cur = lds + (t & (TN_NST - 1)) * 16384;
+#pragma unroll
+    for (int ks = 0; ks < TN_ROWS / 4; ++ks) {
+      const int m = ks * 4 + q;
+      const float keep = (mb + t * TN_ROWS + m < me) ? 1.f : 0.f;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(cur + offA + m * 512) * keep;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(cur + offB + m * 512);
+#pragma unroll
+      for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ca], b[cb], acc[ca][cb], 0, 0, 0);
+    }
+  }
+  float* cp = Cp + (size_t)s * NI * NJ;
+#pragma unroll
+  for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + wi * 64 + 4 * (q * 4 + r) + ca;
+      f32x4 v = {acc[ca][0][r], acc[ca][1][r], acc[ca][2][r], acc[ca][3][r]};
+      *reinterpret_cast<f32x4*>(cp + (size_t)i * NJ + j0 + wj * 64 + 4 * l15) = v;
+    }
+}
+
+// One launch for all split reductions of a backward pass: segment g holds S planes of n floats (plane stride n) and
+// sums them in plane order into out (fixed order -> deterministic).
+#define RED_SEGS 6
+struct RedSegs {
+  const float* part[RED_SEGS];
+  float* out[RED_SEGS];
+  unsigned long long end[RED_SEGS];   // cumulative element counts
+  unsigned long long n[RED_SEGS];
+  int S[RED_SEGS];
+  int count;
+};
+__global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L) {
+  const unsigned long long total = L.end[L.count - 1];
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (unsigned long long)gridDim.x * 256) {
+    int g = 0;
+    while (i >= L.end[g]) ++g;
+    const unsigned long long e = i - (g ? L.end[g - 1] : 0ull);
+    const float* p = L.part[g] + e;
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(size_t)s * n + i];
-    out[i] = a;
+    for (int s = 0; s < L.S[g]; ++s) a += p[(size_t)s * L.n[g]];
+    L.out[g][e] = a;
   }
 }
 
-// column sums (bias grads): part[y][i] = sum over the rows of slab y of dY[m][i]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, float* __restrict__ part, int Mrows,
-                                                     int N, int rows_per) {
+// bias-gradient column sums of the three dY matrices (dh2 | dh1 | dqkv) in one launch: blockIdx.x walks 64-column blocks
+// of the virtual concatenation, blockIdx.y the row slab; part[y][concat col].
+__global__ __launch_bounds__(256) void colsum3_kernel(const float* __restrict__ y0, const float* __restrict__ y1,
+                                                      const float* __restrict__ y2, float* __restrict__ part, int Mrows,
+                                                      int D, int rows_per) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + tx;
+  const int ccol = blockIdx.x * 64 + tx;       // D % 64 == 0, so a block never straddles two matrices
+  const float* src;
+  int N, col;
+  if (ccol < D) { src = y0; N = D; col = ccol; }
+  else if (ccol < 2 * D) { src = y1; N = D; col = ccol - D; }
+  else { src = y2; N = 3 * D; col = ccol - 2 * D; }
   const int mb = blockIdx.y * rows_per, me = min(Mrows, mb + rows_per);
   float a = 0.f;
-  if (col < N)
-    for (int m = mb + ty; m < me; m += 4) a += dY[(size_t)m * N + col];
+  for (int m = mb + ty; m < me; m += 4) a += src[(size_t)m * N + col];
   red[ty][tx] = a;
   __syncthreads();
-  if (ty == 0 && col < N) part[(size_t)blockIdx.y * N + col] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+  if (ty == 0) part[(size_t)blockIdx.y * 5 * D + ccol] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
-                                                        int Cc) {
+// two square transposes in one launch (blockIdx.z picks the matrix)
+__global__ __launch_bounds__(256) void transpose2_kernel(const float* __restrict__ in0, float* __restrict__ out0,
+                                                         const float* __restrict__ in1, float* __restrict__ out1, int R,
+                                                         int Cc) {
   __shared__ float tile[32][33];
+  const float* in = blockIdx.z ? in1 : in0;
+  float* out = blockIdx.z ? out1 : out0;
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int r = ty; r < 32; r += 8)
@@ -581,9 +716,25 @@ struct SelWs {  // workspace layout shared by forward and backward
   size_t bytes;
 };
 
-int split_for(int BT) {
-  int S = (BT + 255) / 256;
-  return S < 1 ? 1 : (S > 16 ? 16 : S);
+// Number of contraction splits of the weight-gradient GEMMs.  Each split of a 128x128 tile is one workgroup that runs
+// at one-SIMD-per-wave speed, so the makespan is set by how evenly tiles*S workgroups fill 256 CUs: pick the S (chunk
+// of >= 128 rows, at most 16 partial planes) that wastes the least of the last "round" for both the DxD and 3DxD GEMMs.
+int split_for(int BT, int D) {
+  int smax = BT / 128;
+  smax = smax < 1 ? 1 : (smax > 16 ? 16 : smax);
+  const int tiles = ((D + 127) / 128) * ((D + 127) / 128);
+  int best = 1;
+  double best_eff = -1.0;
+  for (int S = 1; S <= smax; ++S) {
+    double eff = 1.0;
+    for (int mul = 1; mul <= 3; mul += 2) {
+      const int wgs = tiles * mul * S;
+      const double e = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+      eff = e < eff ? e : eff;
+    }
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = S; }
+  }
+  return best;
 }
 
 SelWs carve(void* ws, int B, int T, int D, int H, int M, int w) {
@@ -604,10 +755,10 @@ SelWs carve(void* ws, int B, int T, int D, int H, int M, int w) {
   s.dS = c.take<float>(BT * H * w);
   s.w1t = c.take<float>((size_t)D * D);
   s.w2t = c.take<float>((size_t)D * D);
-  s.S = split_for((int)BT);
+  s.S = split_for((int)BT, D);
   s.CS = 16;
-  s.part = c.take<float>((size_t)s.S * 3 * D * D);
-  s.cpart = c.take<float>((size_t)s.CS * 3 * D);
+  s.part = c.take<float>((size_t)s.S * 5 * D * D);   // planes of dW2 | dW1 | dWqkv partials (kept until the single reduce)
+  s.cpart = c.take<float>((size_t)s.CS * 5 * D);
   s.bytes = c.bytes();
   return s;
 }
@@ -659,18 +810,13 @@ extern "C" int tspo_selector_forward(const tspo_selector_weights* w, const float
 }
 
 namespace {
-int weight_grad(const float* dY, const float* X, float* dW, float* db, int BT, int NI, int NJ, const SelWs& s,
-                hipStream_t st) {
+int weight_grad(const float* dY, const float* X, float* part, int BT, int NI, int NJ, const SelWs& s, hipStream_t st) {
   const int chunk = ((BT + s.S - 1) / s.S + 3) / 4 * 4;
   dim3 grid((NJ + 127) / 128, (NI + 127) / 128, s.S);
-  hipLaunchKernelGGL(gemm_f32_tn_kernel, grid, dim3(256), 0, st, dY, X, s.part, BT, NI, NJ, chunk);
-  const size_t n = (size_t)NI * NJ;
-  int nb = (int)((n + 255) / 256);
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(nb), dim3(256), 0, st, s.part, dW, n, s.S);
-  const int rows_per = (BT + s.CS - 1) / s.CS;
-  hipLaunchKernelGGL(colsum_kernel, dim3((NI + 63) / 64, s.CS), dim3(256), 0, st, dY, s.cpart, BT, NI, rows_per);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((NI + 255) / 256), dim3(256), 0, st, s.cpart, db, (size_t)NI, s.CS);
+  if (NI % 128 == 0 && NJ % 128 == 0)
+    hipLaunchKernelGGL(gemm_f32_tn_lds_kernel, grid, dim3(256), 0, st, dY, X, part, BT, NI, NJ, chunk);
+  else
+    hipLaunchKernelGGL(gemm_f32_tn_kernel, grid, dim3(256), 0, st, dY, X, part, BT, NI, NJ, chunk);
   return tspo::check_launch("selector weight_grad");
 }
 }  // namespace
@@ -687,16 +833,19 @@ extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const floa
     return tspo::set_err(TSPO_EWORKSPACE, "selector_backward: workspace %zu < %zu", workspace_bytes, s.bytes);
   hipStream_t st = (hipStream_t)stream;
   const int BT = B * T;
-  dim3 tg((D + 31) / 32, (D + 31) / 32);
-  hipLaunchKernelGGL(transpose_kernel, tg, dim3(256), 0, st, w->w1, s.w1t, D, D);
-  hipLaunchKernelGGL(transpose_kernel, tg, dim3(256), 0, st, w->w2, s.w2t, D, D);
+  dim3 tg((D + 31) / 32, (D + 31) / 32, 2);
+  hipLaunchKernelGGL(transpose2_kernel, tg, dim3(256), 0, st, w->w1, s.w1t, w->w2, s.w2t, D, D);
+  const size_t DD = (size_t)D * D;
+  float* part_w2 = s.part;
+  float* part_w1 = s.part + (size_t)s.S * DD;
+  float* part_qkv = s.part + (size_t)s.S * 2 * DD;
   // score -> dh2
   hipLaunchKernelGGL(score_bwd_kernel, dim3((BT + 3) / 4), dim3(256), 0, st, s.h2, txt, dscores, s.dh2, B, T, D, M, tau);
   // mlp.2
-  if (int e = weight_grad(s.dh2, s.h1, g->w2, g->b2, BT, D, D, s, st)) return e;
+  if (int e = weight_grad(s.dh2, s.h1, part_w2, BT, D, D, s, st)) return e;
   if (int e = launch_gemm_nt<EPI_MASK>(s.dh2, s.w2t, nullptr, s.h1, s.dh1, BT, D, D, st)) return e;
   // mlp.0
-  if (int e = weight_grad(s.dh1, s.ctx, g->w1, g->b1, BT, D, D, s, st)) return e;
+  if (int e = weight_grad(s.dh1, s.ctx, part_w1, BT, D, D, s, st)) return e;
   if (int e = launch_gemm_nt<EPI_NONE>(s.dh1, s.w1t, nullptr, nullptr, s.dctx, BT, D, D, st)) return e;
   // banded attention
   const long pairs = (long)BT * H;
@@ -706,7 +855,29 @@ extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const floa
   hipLaunchKernelGGL(band_attn_bwd_kv_kernel, dim3(pb), dim3(256), 0, st, s.qkv, s.P, s.dS, s.dctx, s.dqkv, B, T, D, H,
                      window);
   // q/k/v projections
-  if (int e = weight_grad(s.dqkv, s.xpe, g->wqkv, g->bqkv, BT, 3 * D, D, s, st)) return e;
+  if (int e = weight_grad(s.dqkv, s.xpe, part_qkv, BT, 3 * D, D, s, st)) return e;
+  // bias grads: column sums of dh2 | dh1 | dqkv, then every split reduction (3 weights + 3 biases) in one launch
+  const int rows_per = (BT + s.CS - 1) / s.CS;
+  hipLaunchKernelGGL(colsum3_kernel, dim3(5 * D / 64, s.CS), dim3(256), 0, st, s.dh2, s.dh1, s.dqkv, s.cpart, BT, D,
+                     rows_per);
+  RedSegs L;
+  const float* parts[RED_SEGS] = {part_w2, part_w1, part_qkv, s.cpart, s.cpart + D, s.cpart + 2 * D};
+  float* outs[RED_SEGS] = {g->w2, g->w1, g->wqkv, g->b2, g->b1, g->bqkv};
+  const unsigned long long ns[RED_SEGS] = {DD, DD, 3 * DD, (unsigned long long)D, (unsigned long long)D, 3ull * D};
+  unsigned long long run = 0;
+  for (int i = 0; i < RED_SEGS; ++i) {
+    L.part[i] = parts[i];
+    L.out[i] = outs[i];
+    run += ns[i];
+    L.end[i] = run;
+    // weight partial planes are n apart; bias partial planes are 5*D apart (one row of the concatenated column sums)
+    L.n[i] = i < 3 ? ns[i] : 5ull * D;
+    L.S[i] = i < 3 ? s.S : s.CS;
+  }
+  L.count = RED_SEGS;
+  int nb = (int)((run + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L);
   (void)img;
   return tspo::check_launch("selector_backward");
 }
