@@ -337,14 +337,15 @@ __global__ __launch_bounds__(256) void pg_grad_kernel(const float* __restrict__ 
                                                       float* __restrict__ dlogits, float* __restrict__ loss) {
   extern __shared__ __attribute__((aligned(16))) int lds_idx[];  // G*k ints then G floats
   float* a = reinterpret_cast<float*>(lds_idx + (size_t)G * k);
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x;   // blockIdx.y: 256-frame slice of the row
   for (int i = tid; i < G * k; i += 256) lds_idx[i] = (int)idx[(size_t)b * G * k + i];
   for (int g = tid; g < G; g += 256) a[g] = adv[(size_t)b * G + g];
   __syncthreads();
   float sumA = 0.f;
   for (int g = 0; g < G; ++g) sumA += a[g];
   const float invk = 1.f / (float)k, invG = 1.f / (float)G;
-  for (int t = tid; t < T; t += 256) {
+  const int t = blockIdx.y * 256 + tid;
+  if (t < T) {
     const float p = expf(logp[(size_t)b * T + t]);
     float acc = 0.f;
     for (int g = 0; g < G; ++g) {
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void pg_grad_kernel(const float* __restrict__ 
     }
     dlogits[(size_t)b * T + t] = -invG * acc * scale;
   }
-  if (loss && tid == 0) loss[b] = -sumA * invG;
+  if (loss && tid == 0 && blockIdx.y == 0) loss[b] = -sumA * invG;
 }
 
 extern "C" int tspo_pg_grad_logits(const float* logp, const int64_t* idx, const float* adv, int B, int G, int T, int k,
@@ -371,7 +372,7 @@ extern "C" int tspo_pg_grad_logits(const float* logp, const int64_t* idx, const 
   const size_t lds = (size_t)G * k * 4 + (size_t)G * 4;
   TSPO_REQUIRE(lds <= 64 * 1024, "pg_grad_logits: G*k=%d too large for LDS", G * k);
   if (B == 0) return TSPO_OK;
-  hipLaunchKernelGGL(pg_grad_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, logp, idx, adv, G, T, k, scale,
+  hipLaunchKernelGGL(pg_grad_kernel, dim3(B, (T + 255) / 256), dim3(256), lds, (hipStream_t)stream, logp, idx, adv, G, T, k, scale,
                      dlogits, loss);
   return tspo::check_launch("pg_grad_logits");
 }

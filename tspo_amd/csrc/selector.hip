@@ -284,17 +284,27 @@ __global__ __launch_bounds__(256) void band_attn_fwd_kernel(const float* __restr
     qv[c] = e < hd ? qkv[row * ld + h * hd + e] : 0.f;
   }
   float s0 = -INFINITY, s1 = -INFINITY;
-  for (int j = 0; j < n; ++j) {
-    const float* kr = qkv + (rowb + lo + j) * ld + D + h * hd;
-    float d = 0.f;
+  for (int j0 = 0; j0 < n; j0 += 4) {   // 4 keys per trip: their loads are issued together (rows clamped, extras unused)
+    float d[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int e = hl + 32 * c;
-      if (e < hd) d += qv[c] * kr[e];
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, n - 1);
+      const float* kr = qkv + (rowb + lo + j) * ld + D + h * hd;
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e = hl + 32 * c;
+        if (e < hd) a += qv[c] * kr[e];
+      }
+      d[u] = a;
     }
-    d = half_sum(d) * scale;
-    if (j == hl) s0 = d;
-    if (j == hl + 32) s1 = d;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u;
+      const float dd = half_sum(d[u]) * scale;
+      if (j < n && j == hl) s0 = dd;
+      if (j < n && j == hl + 32) s1 = dd;
+    }
   }
   const float m = half_max(fmaxf(s0, s1));
   const float e0 = hl < n ? expf(s0 - m) : 0.f;
@@ -304,14 +314,24 @@ __global__ __launch_bounds__(256) void band_attn_fwd_kernel(const float* __restr
   if (hl < w) P[pair * w + hl] = p0;
   if (hl + 32 < w) P[pair * w + hl + 32] = p1;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < n; ++j) {
-    const float pj = j < 32 ? __shfl(p0, j, 32) : __shfl(p1, j - 32, 32);
-    const float* vr = qkv + (rowb + lo + j) * ld + 2 * D + h * hd;
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    float vv[4][4], pj[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int e = hl + 32 * c;
-      if (e < hd) acc[c] += pj * vr[e];
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, n - 1);
+      const float pr = j < 32 ? __shfl(p0, j, 32) : __shfl(p1, j - 32, 32);
+      pj[u] = j0 + u < n ? pr : 0.f;
+      const float* vr = qkv + (rowb + lo + j) * ld + 2 * D + h * hd;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e = hl + 32 * c;
+        vv[u][c] = e < hd ? vr[e] : 0.f;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] += pj[u] * vv[u][c];
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -421,6 +441,300 @@ __global__ __launch_bounds__(256) void band_attn_bwd_kv_kernel(const float* __re
       dqkv[row * ld + D + h * hd + e] = dk[c];
       dqkv[row * ld + 2 * D + h * hd + e] = dv[c];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// MFMA form of the banded attention for the production shapes (head width a multiple of 16 up to 128, window <= 17):
+// one wave owns a block of 16 consecutive rows of one (video, head).  All three kernels work on TRANSPOSED score tiles
+// S^T[key][query] (2 tiles of 16 keys cover the 16 + w - 1 keys any of the 16 queries can see): in the MFMA result
+// layout a lane then holds, for its query column l15, the keys 4q+r (+16) — softmax reductions are 8 in-lane values plus
+// two cross-lane steps (xor 16, 32), and the same registers are directly the A operand (row = query l15, k <-> key
+// 4q+r) of the second product, whose B operand loads the matching rows of V (or K / Q / dctx) as contiguous float4 per
+// lane: no LDS, no transposes.  Everything is fp32 (v_mfma_f32_16x16x4_f32).
+template <int HD>
+struct HeadCols {   // output columns of one head split into lane-vector groups: 64-wide (float4/lane), then 32 (float2), then 16
+  static constexpr int N4 = HD / 64;
+  static constexpr bool HAS2 = (HD % 64) >= 32;
+  static constexpr bool HAS1 = (HD % 32) >= 16;
+  static constexpr int BASE2 = 64 * N4;
+  static constexpr int BASE1 = BASE2 + (HAS2 ? 32 : 0);
+  static constexpr int TILES = HD / 16;
+};
+
+// acc[tt][r] += sum_d Arows[key kb+16tt+4q+r... (as MFMA row l15)][d] * Brows[query (MFMA col l15)][d]
+// arow[tt] / brow: clamped absolute row pointers (already offset to the head's first column) for this lane's l15.
+template <int HD>
+__device__ __forceinline__ void band_scores_T(const float* const (&arow)[2], const float* brow, int q, f32x4 (&acc)[2]) {
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ch = 0; ch < HD / 16; ++ch) {
+    const f32x4 bf = *reinterpret_cast<const f32x4*>(brow + ch * 16 + 4 * q);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow[0] + ch * 16 + 4 * q);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow[1] + ch * 16 + 4 * q);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[st], bf[st], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[st], bf[st], acc[1], 0, 0, 0);
+    }
+  }
+}
+
+// out[tile] += sum over the 32 tile rows of coef[tt][r] (A: MFMA row l15) x mat[row rb+16tt+4q+r][head cols] (B).
+// `mat` points at the head's first column of row 0 of the video; rows are clamped to [0, T-1] (their coefficient is 0).
+template <int HD>
+__device__ __forceinline__ void band_rows_x_mat(const f32x4 (&coef)[2], const float* mat, size_t ld, int rb, int T, int q,
+                                                int l15, f32x4 (&out)[HD / 16]) {
+  using HC = HeadCols<HD>;
+#pragma unroll
+  for (int c = 0; c < HC::TILES; ++c) out[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = rb + 16 * tt + 4 * q + r;
+      row = row < 0 ? 0 : (row > T - 1 ? T - 1 : row);
+      const float* mr = mat + (size_t)row * ld;
+      const float cf = coef[tt][r];
+#pragma unroll
+      for (int g = 0; g < HC::N4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(mr + 64 * g + 4 * l15);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[4 * g + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, v[c], out[4 * g + c], 0, 0, 0);
+      }
+      if (HC::HAS2) {
+        const float2 v = *reinterpret_cast<const float2*>(mr + HC::BASE2 + 2 * l15);
+        out[4 * HC::N4] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, v.x, out[4 * HC::N4], 0, 0, 0);
+        out[4 * HC::N4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, v.y, out[4 * HC::N4 + 1], 0, 0, 0);
+      }
+      if (HC::HAS1) {
+        const float v = mr[HC::BASE1 + l15];
+        out[HC::TILES - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, v, out[HC::TILES - 1], 0, 0, 0);
+      }
+    }
+}
+
+// store out (rows i0+4q+r of the block, head columns in the lane-vector grouping) to dst (head's first column, row 0)
+template <int HD>
+__device__ __forceinline__ void band_store_rows(const f32x4 (&out)[HD / 16], float* dst, size_t ld, int i0, int T, int q,
+                                                int l15) {
+  using HC = HeadCols<HD>;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = i0 + 4 * q + r;
+    if (t < T) {
+      float* dr = dst + (size_t)t * ld;
+#pragma unroll
+      for (int g = 0; g < HC::N4; ++g) {
+        const f32x4 v = {out[4 * g][r], out[4 * g + 1][r], out[4 * g + 2][r], out[4 * g + 3][r]};
+        *reinterpret_cast<f32x4*>(dr + 64 * g + 4 * l15) = v;
+      }
+      if (HC::HAS2) *reinterpret_cast<float2*>(dr + HC::BASE2 + 2 * l15) = make_float2(out[4 * HC::N4][r], out[4 * HC::N4 + 1][r]);
+      if (HC::HAS1) dr[HC::BASE1 + l15] = out[HC::TILES - 1][r];
+    }
+  }
+}
+
+struct BandBlk {   // wave -> (video, head, 16-row block)
+  int b, h, i0;
+  bool live;
+};
+__device__ __forceinline__ BandBlk band_block(int B, int T, int H) {
+  const int nblk = (T + 15) / 16;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  BandBlk k;
+  k.live = wave < (long)B * nblk * H;
+  const long wv = k.live ? wave : 0;
+  k.h = (int)(wv % H);
+  const long rest = wv / H;
+  k.i0 = (int)(rest % nblk) * 16;
+  k.b = (int)(rest / nblk);
+  return k;
+}
+__device__ __forceinline__ float xor_sum_hi(float v) {   // over the 4 lanes that share l15
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float xor_max_hi(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void band_attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                                 float* __restrict__ P, int B, int T, int D, int H, int w) {
+  const BandBlk k = band_block(B, T, H);
+  if (!k.live) return;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+  const size_t ld = (size_t)3 * D;
+  const float* base = qkv + (size_t)k.b * T * ld + k.h * HD;   // row 0 of the video, q columns of the head
+  const int kb = k.i0 - w / 2;                                   // first key of the tile pair (may be < 0)
+  const int t = k.i0 + l15;                                      // this lane's query (MFMA column)
+  const int tq = t < T ? t : T - 1;
+  const float* arow[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    int kr = kb + 16 * tt + l15;
+    kr = kr < 0 ? 0 : (kr > T - 1 ? T - 1 : kr);
+    arow[tt] = base + (size_t)kr * ld + D;
+  }
+  f32x4 sc[2];
+  band_scores_T<HD>(arow, base + (size_t)tq * ld, q, sc);
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int lo = max(0, tq - w / 2), hi = min(T - 1, tq - w / 2 + w - 1);
+  float m = -INFINITY;
+  bool ok[2][4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb + 16 * tt + 4 * q + r;
+      ok[tt][r] = key >= lo && key <= hi;
+      sc[tt][r] = ok[tt][r] ? sc[tt][r] * scale : -INFINITY;
+      m = fmaxf(m, sc[tt][r]);
+    }
+  m = xor_max_hi(m);
+  float l = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[tt][r] = ok[tt][r] ? expf(sc[tt][r] - m) : 0.f;
+      l += sc[tt][r];
+    }
+  l = xor_sum_hi(l);
+  const size_t pair = ((size_t)k.b * T + tq) * H + k.h;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[tt][r] = sc[tt][r] / l;
+      const int slot = kb + 16 * tt + 4 * q + r - lo;
+      if (t < T && slot >= 0 && slot < w) P[pair * w + slot] = sc[tt][r];   // slots past the clipped window hold 0
+    }
+  f32x4 out[HD / 16];
+  band_rows_x_mat<HD>(sc, base + 2 * D, ld, kb, T, q, l15, out);
+  band_store_rows<HD>(out, ctx + (size_t)k.b * T * D + k.h * HD, (size_t)D, k.i0, T, q, l15);
+}
+
+// backward part 1 (MFMA): dS (scaled) and dq for a block of 16 queries
+template <int HD>
+__global__ __launch_bounds__(256) void band_attn_bwd_q_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                                   const float* __restrict__ dctx,
+                                                                   float* __restrict__ dqkv, float* __restrict__ dS, int B,
+                                                                   int T, int D, int H, int w) {
+  const BandBlk k = band_block(B, T, H);
+  if (!k.live) return;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+  const size_t ld = (size_t)3 * D;
+  const float* base = qkv + (size_t)k.b * T * ld + k.h * HD;
+  const int kb = k.i0 - w / 2;
+  const int t = k.i0 + l15;
+  const int tq = t < T ? t : T - 1;
+  const float* arow[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    int kr = kb + 16 * tt + l15;
+    kr = kr < 0 ? 0 : (kr > T - 1 ? T - 1 : kr);
+    arow[tt] = base + (size_t)kr * ld + 2 * D;   // V rows
+  }
+  f32x4 dp[2];
+  band_scores_T<HD>(arow, dctx + ((size_t)k.b * T + tq) * D + k.h * HD, q, dp);
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int lo = max(0, tq - w / 2), hi = min(T - 1, tq - w / 2 + w - 1);
+  const size_t pair = ((size_t)k.b * T + tq) * H + k.h;
+  f32x4 pv[2];
+  float dot = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb + 16 * tt + 4 * q + r;
+      const bool ok = key >= lo && key <= hi;
+      pv[tt][r] = ok ? P[pair * w + (key - lo)] : 0.f;
+      dot += pv[tt][r] * dp[tt][r];
+    }
+  dot = xor_sum_hi(dot);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ds = pv[tt][r] * (dp[tt][r] - dot) * scale;   // 0 outside the window (p == 0)
+      dp[tt][r] = ds;
+      const int slot = kb + 16 * tt + 4 * q + r - lo;
+      if (t < T && slot >= 0 && slot < w) dS[pair * w + slot] = ds;
+    }
+  f32x4 out[HD / 16];
+  band_rows_x_mat<HD>(dp, base + D, ld, kb, T, q, l15, out);   // dq = dS . K
+  band_store_rows<HD>(out, dqkv + (size_t)k.b * T * ld + k.h * HD, ld, k.i0, T, q, l15);
+}
+
+// backward part 2 (MFMA): dk, dv for a block of 16 keys, gathered over the <= 16 + w - 1 queries that see them
+template <int HD>
+__global__ __launch_bounds__(256) void band_attn_bwd_kv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                                    const float* __restrict__ dS,
+                                                                    const float* __restrict__ dctx,
+                                                                    float* __restrict__ dqkv, int B, int T, int D, int H,
+                                                                    int w) {
+  const BandBlk k = band_block(B, T, H);
+  if (!k.live) return;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, q = lane >> 4;
+  const size_t ld = (size_t)3 * D;
+  const int j = k.i0 + l15;                       // this lane's key (MFMA row of the coefficient operand)
+  const int tb = k.i0 - (w - 1 - w / 2);          // first query of the tile pair: j-(w-1-w/2) <= t <= j+w/2
+  f32x4 cds[2], cp[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = tb + 16 * tt + 4 * q + r;
+      float vds = 0.f, vp = 0.f;
+      if (t >= 0 && t < T && j < T) {
+        const int lo = max(0, t - w / 2), hi = min(T - 1, t - w / 2 + w - 1);
+        if (j >= lo && j <= hi) {
+          const size_t pr = (((size_t)k.b * T + t) * H + k.h) * w + (j - lo);
+          vds = dS[pr];
+          vp = P[pr];
+        }
+      }
+      cds[tt][r] = vds;
+      cp[tt][r] = vp;
+    }
+  f32x4 out[HD / 16];
+  float* dst = dqkv + (size_t)k.b * T * ld + k.h * HD;
+  band_rows_x_mat<HD>(cds, qkv + (size_t)k.b * T * ld + k.h * HD, ld, tb, T, q, l15, out);   // dk = dS^T . Q
+  band_store_rows<HD>(out, dst + D, ld, k.i0, T, q, l15);
+  band_rows_x_mat<HD>(cp, dctx + (size_t)k.b * T * D + k.h * HD, (size_t)D, tb, T, q, l15, out);   // dv = P^T . dctx
+  band_store_rows<HD>(out, dst + 2 * D, ld, k.i0, T, q, l15);
+}
+
+// which == 0: forward, 1: backward-q, 2: backward-kv.  Returns false when the shape needs the generic kernels.
+template <int HD>
+void launch_band_mfma(int which, const float* qkv, float* ctx, float* P, const float* dctx, float* dqkv, float* dS, int B,
+                      int T, int D, int H, int w, hipStream_t st) {
+  const long waves = (long)B * ((T + 15) / 16) * H;
+  const dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+  if (which == 0)
+    hipLaunchKernelGGL((band_attn_fwd_mfma_kernel<HD>), grid, blk, 0, st, qkv, ctx, P, B, T, D, H, w);
+  else if (which == 1)
+    hipLaunchKernelGGL((band_attn_bwd_q_mfma_kernel<HD>), grid, blk, 0, st, qkv, (const float*)P, dctx, dqkv, dS, B, T, D, H, w);
+  else
+    hipLaunchKernelGGL((band_attn_bwd_kv_mfma_kernel<HD>), grid, blk, 0, st, qkv, (const float*)P, (const float*)dS, dctx, dqkv,
+                       B, T, D, H, w);
+}
+bool band_mfma(int which, const float* qkv, float* ctx, float* P, const float* dctx, float* dqkv, float* dS, int B, int T,
+               int D, int H, int w, hipStream_t st) {
+  if (w > 17 || D % H) return false;
+  switch (D / H) {
+    case 16: launch_band_mfma<16>(which, qkv, ctx, P, dctx, dqkv, dS, B, T, D, H, w, st); return true;
+    case 32: launch_band_mfma<32>(which, qkv, ctx, P, dctx, dqkv, dS, B, T, D, H, w, st); return true;
+    case 64: launch_band_mfma<64>(which, qkv, ctx, P, dctx, dqkv, dS, B, T, D, H, w, st); return true;
+    case 96: launch_band_mfma<96>(which, qkv, ctx, P, dctx, dqkv, dS, B, T, D, H, w, st); return true;
+    case 128: launch_band_mfma<128>(which, qkv, ctx, P, dctx, dqkv, dS, B, T, D, H, w, st); return true;
+    default: return false;
   }
 }
 
@@ -639,17 +953,20 @@ struct RedSegs {
   int S[RED_SEGS];
   int count;
 };
-__global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L) {
-  const unsigned long long total = L.end[L.count - 1];
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (unsigned long long)gridDim.x * 256) {
+__global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L) {   // every n is a multiple of 4 (D % 64 == 0)
+  const unsigned long long total4 = L.end[L.count - 1] >> 2;
+  for (unsigned long long i4 = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i4 < total4;
+       i4 += (unsigned long long)gridDim.x * 256) {
+    const unsigned long long i = i4 << 2;
     int g = 0;
     while (i >= L.end[g]) ++g;
     const unsigned long long e = i - (g ? L.end[g - 1] : 0ull);
     const float* p = L.part[g] + e;
-    float a = 0.f;
-    for (int s = 0; s < L.S[g]; ++s) a += p[(size_t)s * L.n[g]];
-    L.out[g][e] = a;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    const int S = L.S[g];
+    const size_t stride = L.n[g];
+    for (int s = 0; s < S; ++s) a += *reinterpret_cast<const f32x4*>(p + (size_t)s * stride);
+    *reinterpret_cast<f32x4*>(L.out[g] + e) = a;
   }
 }
 
@@ -797,8 +1114,9 @@ extern "C" int tspo_selector_forward(const tspo_selector_weights* w, const float
   hipLaunchKernelGGL(posenc_add_kernel, dim3(nb), dim3(256), 0, st, img, s.xpe, T, D, tot);
   if (int e = launch_gemm_nt<EPI_NONE>(s.xpe, w->wqkv, w->bqkv, nullptr, s.qkv, BT, 3 * D, D, st)) return e;
   const long pairs = (long)BT * H;
-  hipLaunchKernelGGL(band_attn_fwd_kernel, dim3((unsigned)((pairs + 7) / 8)), dim3(256), 0, st, s.qkv, s.ctx, s.P, B, T,
-                     D, H, window);
+  if (!band_mfma(0, s.qkv, s.ctx, s.P, nullptr, nullptr, nullptr, B, T, D, H, window, st))
+    hipLaunchKernelGGL(band_attn_fwd_kernel, dim3((unsigned)((pairs + 7) / 8)), dim3(256), 0, st, s.qkv, s.ctx, s.P, B, T,
+                       D, H, window);
   if (int e = launch_gemm_nt<EPI_RELU>(s.ctx, w->w1, w->b1, nullptr, s.h1, BT, D, D, st)) return e;
   if (int e = launch_gemm_nt<EPI_RESID>(s.h1, w->w2, w->b2, img, s.h2, BT, D, D, st)) return e;
   hipLaunchKernelGGL(score_fwd_kernel, dim3((BT + 3) / 4), dim3(256), 0, st, s.h2, txt, clip, scores, B, T, D, M, tau);
@@ -850,10 +1168,12 @@ extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const floa
   // banded attention
   const long pairs = (long)BT * H;
   const unsigned pb = (unsigned)((pairs + 7) / 8);
-  hipLaunchKernelGGL(band_attn_bwd_q_kernel, dim3(pb), dim3(256), 0, st, s.qkv, s.P, s.dctx, s.dqkv, s.dS, B, T, D, H,
-                     window);
-  hipLaunchKernelGGL(band_attn_bwd_kv_kernel, dim3(pb), dim3(256), 0, st, s.qkv, s.P, s.dS, s.dctx, s.dqkv, B, T, D, H,
-                     window);
+  if (!band_mfma(1, s.qkv, nullptr, s.P, s.dctx, s.dqkv, s.dS, B, T, D, H, window, st))
+    hipLaunchKernelGGL(band_attn_bwd_q_kernel, dim3(pb), dim3(256), 0, st, s.qkv, s.P, s.dctx, s.dqkv, s.dS, B, T, D, H,
+                       window);
+  if (!band_mfma(2, s.qkv, nullptr, s.P, s.dctx, s.dqkv, s.dS, B, T, D, H, window, st))
+    hipLaunchKernelGGL(band_attn_bwd_kv_kernel, dim3(pb), dim3(256), 0, st, s.qkv, s.P, s.dS, s.dctx, s.dqkv, B, T, D, H,
+                       window);
   // q/k/v projections
   if (int e = weight_grad(s.dqkv, s.xpe, part_qkv, BT, 3 * D, D, s, st)) return e;
   // bias grads: column sums of dh2 | dh1 | dqkv, then every split reduction (3 weights + 3 biases) in one launch
@@ -875,7 +1195,7 @@ extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const floa
     L.S[i] = i < 3 ? s.S : s.CS;
   }
   L.count = RED_SEGS;
-  int nb = (int)((run + 255) / 256);
+  int nb = (int)((run / 4 + 255) / 256);
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L);
   (void)img;
