@@ -122,8 +122,7 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 // One workgroup = 64 x (32*WN) outputs, NWM x 2 waves of (64/NWM) x (16*WN); 3-deep ring with counted vmcnt waits.
 // WN = 3 (64x96 tiles) is used when N % 96 == 0: for D = 768 that makes BT=2048 x 768 exactly 256 workgroups (one
 // per CU) and x 2304 exactly 3 per CU, instead of 1.5 / 4.5 with 64x64 tiles, and gives 48 MFMAs per barrier.
-#define NT_NST 3
-template <int EPI, int WN, int NWM>
+template <int EPI, int WN, int NWM, int NT_NST>
 __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ R, float* __restrict__ C,
@@ -188,13 +187,14 @@ __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float*
   for (int j = 0; j < WN; ++j) offW[j] = 8192 + (wn * 16 * WN + j * 16 + l15) * 128;
   const int sw = l15 & 7;
   stage(0, 0);
-  if (nk > 1) stage(1, 1);
+  if (NT_NST == 3 && nk > 1) stage(1, 1);
   int ring = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) wait_one_ahead();
+    // 3-deep: slab kt+1 stays in flight across the wait; 2-deep (more workgroups per CU instead): everything has landed
+    if (NT_NST == 3 && kt + 1 < nk) wait_one_ahead();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // slab kt visible to all waves; compute(kt-1) done everywhere -> its slot is free
-    if (kt + 2 < nk) stage(kt + 2, ring >= 1 ? ring - 1 : NT_NST - 1);
+    if (kt + NT_NST - 1 < nk) stage(kt + NT_NST - 1, ring >= 1 ? ring - 1 : NT_NST - 1);
     const char* cur = lds + ring * SLAB;
     ring = ring + 1 == NT_NST ? 0 : ring + 1;
 #pragma unroll
@@ -238,10 +238,15 @@ template <int EPI>
 int launch_gemm_nt(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
                    hipStream_t st) {
   const int mt = (M + 63) / 64;
-  if (K % 32 == 0 && N % 96 == 0)
-    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
-  else if (K % 32 == 0)
-    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 2, 4>), dim3(N / 64, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
+  // ring depth 3 keeps two workgroups (16 waves) per CU; when the grid holds more than two workgroups per CU a 2-deep
+  // ring (40 KB) lets three run at once instead of leaving the third for a half-empty second round
+  if (K % 32 == 0 && N % 96 == 0) {
+    if ((long)(N / 96) * mt > 512)
+      hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4, 2>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
+    else
+      hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4, 3>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
+  } else if (K % 32 == 0)
+    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 2, 4, 3>), dim3(N / 64, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
   else
     hipLaunchKernelGGL((gemm_f32_nt_kernel<EPI>), dim3(N / 64, mt), dim3(256), 0, st, A, W, bias, R, C, M, N, K);
   return tspo::check_launch("selector gemm_nt");
