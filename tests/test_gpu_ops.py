@@ -266,6 +266,53 @@ def test_adamw_matches_oracle_on_identical_inputs():
         np.testing.assert_allclose(v.cpu().numpy(), vo.numpy(), rtol=1e-5, atol=1e-12)
 
 
+# every head-width instantiation of the MFMA banded attention (16..128), ragged T (not a multiple of 16, shorter than
+# the window), odd / maximal windows, and the shapes that must fall back to the generic kernels (w > 17, head width 24)
+SHAPE_CASES = [
+    ("hd16_T5", 1, 5, 128, 8, 12),
+    ("hd32_ragged", 2, 37, 256, 8, 12),
+    ("hd64_w5", 1, 50, 512, 8, 5),
+    ("hd128_w17", 2, 33, 1024, 8, 17),
+    ("hd96_w1", 1, 19, 768, 8, 1),
+    ("hd96_w18_generic", 1, 40, 768, 8, 18),
+    ("hd24_generic", 1, 20, 192, 8, 12),
+    ("hd64_h4_T300", 1, 300, 256, 4, 12),
+]
+
+
+@pytest.mark.parametrize("case", SHAPE_CASES, ids=[c[0] for c in SHAPE_CASES])
+def test_selector_fwd_bwd_vs_oracle_autograd(case):
+    _, B, T, D, H, w = case
+    tau, M = 0.05, 2
+    img, txt = synth.normal((B, T, D), 1200 + T), synth.normal((B, M, D), 1201 + T)
+    clip, ds = synth.normal((B, T), 1202, 0.1), synth.normal((B, T), 1203, 0.01)
+    state = synth.selector_state(D, seed=40 + H, std=0.5 / np.sqrt(D), bias_std=0.05)
+    flat = flat_from_state(state, D)
+    s, h, ws = ops.selector_forward(flat, G_(img), G_(txt), G_(clip), H, w, tau)
+    fg = torch.zeros_like(flat)
+    ops.selector_backward(flat, fg, G_(img), G_(txt), G_(ds), H, w, tau, ws)
+    params = {k: T_(v).clone().requires_grad_(k in O.SELECTOR_KEYS and "ffn_o" not in k) for k, v in state.items()}
+    loss = 0.0
+    for b in range(B):
+        so, ho = O.selector_forward(params, T_(img[b]), T_(txt[b]), T_(clip[b]), w, tau, H)
+        np.testing.assert_allclose(s[b].cpu().numpy(), so.detach().numpy(), rtol=5e-5, atol=5e-5 / tau)
+        np.testing.assert_allclose(h[b].cpu().numpy(), ho[0].detach().numpy(), rtol=2e-4, atol=5e-5)
+        loss = loss + (so * T_(ds[b])).sum()
+    loss.backward()
+    offs = ops.flat_offsets(D)
+    qb = params["temporal.Self_q.bias"].grad.abs().max().item()
+    for pn in O.SELECTOR_KEYS:
+        off, shape = offs[pn]
+        got = fg[off:off + int(np.prod(shape))].cpu().numpy()
+        if "ffn_o" in pn:
+            assert np.all(got == 0)
+        elif pn == "temporal.Self_k.bias":
+            assert np.abs(got).max() <= 1e-4 * max(qb, 1e-12)     # mathematically zero (see the golden test)
+        else:
+            ref = params[pn].grad.numpy().flatten()
+            np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-5 * max(np.abs(ref).max(), 1e-12))
+
+
 def test_selector_backward_batched_sums():
     """grads of a batch == sum of per-video grads (what the DP all-reduce relies on)."""
     B, T, D, H, M, w, tau = 3, 96, 64, 8, 1, 12, 0.025
