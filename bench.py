@@ -222,6 +222,16 @@ def main():
     fps = frames / sec
     assert out["idx"].shape == (B, min(T, k)) and bool((out["idx"][:, 1:] > out["idx"][:, :-1]).all())
 
+    # ---- split: score + select only (features resident), SURVEY 8(d) ----------
+    feats_res = scorer.encode(pixels)
+
+    def select_step():
+        sc, _ = scorer.score(feats_res, txt)
+        out["idx2"] = ops.topk_sorted(sc, k)
+
+    sel_sec = timed(select_step, max(a.steps, 20), 3) / max(a.steps, 20)
+    assert torch.equal(out["idx2"], out["idx"])
+
     # ---- rollouts / s (policy side of one TSPO step, configs[2]) --------------
     rollouts = None
     if not a.no_rollouts:
@@ -280,6 +290,7 @@ def main():
             "rollouts_config": None if rollouts is None else {"workload": "configs[2] policy step (reward LLM excluded)",
                                                               "B": 4, "T": 512, "G": 8, "k": 16},
             "encode_tflops": round((gemm_flops_per_frame(c) + attn_flops_per_frame(c)) * fps / 1e12, 1),
+            "split_ms": {"encode": round(sec / a.steps * 1e3 - sel_sec * 1e3, 3), "score_select": round(sel_sec * 1e3, 3)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
