@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry-run aid: every rank uses cuda:0")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = torch default)")
+    ap.add_argument("--no-ln-fold", action="store_true", help="A/B: stand-alone LayerNorm passes instead of folding them into the GEMMs")
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -178,6 +179,8 @@ def main():
 
     from tspo_amd import ops
     from tspo_amd.pipeline import FrameScorer, PolicyTrainer
+    if a.no_ln_fold:
+        ops.FOLD_LAYERNORM = False
 
     c = CLIP_L14
     B, T, k = a.videos, a.frames, a.topk
@@ -285,7 +288,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: TSPO-0.4B frame selection (CLIP-L/14 encode + scoring head + top-k)",
                        "frames_per_video": T, "videos_per_gpu_per_step": B, "topk": k, "window": 12, "tau": 0.025,
-                       "pixels": a.pixels, "weights": "random-init CLIP-L/14 + selector", "parallelism": f"dp{world}"},
+                       "pixels": a.pixels, "weights": "random-init CLIP-L/14 + selector", "parallelism": f"dp{world}",
+                       "layernorm": "stand-alone" if a.no_ln_fold else "folded into GEMMs"},
             "rollouts_per_s": None if rollouts is None else round(rollouts, 1),
             "rollouts_config": None if rollouts is None else {"workload": "configs[2] policy step (reward LLM excluded)",
                                                               "B": 4, "T": 512, "G": 8, "k": 16},

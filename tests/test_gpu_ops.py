@@ -391,12 +391,20 @@ def test_clip_vit_forward_70_frames_production_kernels():
     with torch.no_grad():
         ref = O.clip_vit_forward(w, O.clip_normalize_pixels(T_(u8)), num_heads=cfg["heads"], patch=cfg["patch"]).numpy()
     W = ops.ClipVitWeights({k: T_(v) for k, v in state.items()}, cfg, DEV)
-    feat = ops.clip_vit_forward(W, G_(u8)).cpu().numpy()
     scale = np.abs(ref).max()
-    err = np.abs(feat - ref).max() / scale
-    cos = (feat * ref).sum(-1) / np.linalg.norm(feat, axis=-1) / np.linalg.norm(ref, axis=-1)
-    print(f"\n[clip_l14 x70] max|err|/max|ref| {err:.4f}, min cos {cos.min():.6f}")
-    assert err < 3e-2 and cos.min() > 0.999
+    feats = {}
+    # at this size the LayerNorms are folded into the GEMMs (statistics from the residual epilogues); the stand-alone
+    # LayerNorm passes stay reachable through the hook - both must meet the same tolerance against the oracle
+    for fold in (True, False):
+        feat = ops.clip_vit_forward(W, G_(u8), fold_layernorm=fold).cpu().numpy()
+        err = np.abs(feat - ref).max() / scale
+        cos = (feat * ref).sum(-1) / np.linalg.norm(feat, axis=-1) / np.linalg.norm(ref, axis=-1)
+        print(f"\n[clip_l14 x70, fold_layernorm={fold}] max|err|/max|ref| {err:.4f}, min cos {cos.min():.6f}")
+        assert err < 3e-2 and cos.min() > 0.999
+        feats[fold] = feat
+    d = np.abs(feats[True] - feats[False]).max() / scale
+    print(f"[clip_l14 x70] folded vs stand-alone LayerNorm: max|diff|/max|ref| {d:.4f}")
+    assert d < 3e-2
 
 
 def _clip_ref_bf16_weights(cfg, n):

@@ -345,6 +345,9 @@ __global__ __launch_bounds__(256, 2) void clip_attn_kernel(const bf16_t* __restr
 // ===========================================================================
 struct ClipWs {
   bf16_t *x, *h, *qkv, *a, *u, *patches, *pooled;
+  // LayerNorm-folded path: row statistics, their per-slice partials, and the current layer's folded weights
+  float *stats, *spart, *cq, *dq, *c1, *d1;
+  bf16_t *wqkv_f, *w1_f;
   size_t bytes;
 };
 
@@ -361,6 +364,14 @@ ClipWs clip_carve(void* ws, const tspo_clip_config& c, int n) {
   w.u = cv.take<bf16_t>(M * c.mlp);
   w.patches = cv.take<bf16_t>((size_t)n * P * Kp);
   w.pooled = cv.take<bf16_t>((size_t)n * c.hidden);
+  w.stats = cv.take<float>(M * 2);
+  w.spart = cv.take<float>(M * (size_t)(c.hidden / 64) * 2);
+  w.cq = cv.take<float>((size_t)3 * c.hidden);
+  w.dq = cv.take<float>((size_t)3 * c.hidden);
+  w.c1 = cv.take<float>((size_t)c.mlp);
+  w.d1 = cv.take<float>((size_t)c.mlp);
+  w.wqkv_f = cv.take<bf16_t>((size_t)3 * c.hidden * c.hidden);
+  w.w1_f = cv.take<bf16_t>((size_t)c.mlp * c.hidden);
   w.bytes = cv.bytes();
   return w;
 }
@@ -409,6 +420,95 @@ struct Prof {
     for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]);
   }
 };
+
+// ---------------------------------------------------------------------------
+// LayerNorm folded into the GEMMs around it (large batches).  LN(x) W^T = rstd * (x W'^T - mu * c) + (b + W beta) with
+// W' = gamma o W and c[n] = sum_k W'[n,k]: the consumer GEMM reads the raw residual stream and its epilogue applies the
+// per-row (mu, rstd); those come from partial sums the producer GEMM's residual epilogue writes (GE_RESID_ST), so the
+// 48 per-layer LayerNorm passes (read + write of the whole [M, hidden] stream each) disappear.
+// Fold of one weight matrix; one wave per output row n.  W' is rounded to bf16 exactly once (RNE) and c is the sum of the
+// ROUNDED values, i.e. of what the MFMA multiplies, so the mean subtraction cancels exactly.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int N, int K, bf16_t* __restrict__ Wf, float* __restrict__ c,
+                                                      float* __restrict__ d) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const bf16_t* wr = W + (size_t)n * K;
+  bf16_t* fr = Wf + (size_t)n * K;
+  float cs = 0.f, ds = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(wr + k);
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + k), g1 = *reinterpret_cast<const f32x4*>(gamma + k + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + k), b1 = *reinterpret_cast<const f32x4*>(beta + k + 4);
+    const float gm[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+    const float bt[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float w0 = __uint_as_float(u[j] << 16), w1 = __uint_as_float(u[j] & 0xffff0000u);
+      o[j] = pack_bf16x2(w0 * gm[2 * j], w1 * gm[2 * j + 1]);
+      cs += __uint_as_float(o[j] << 16) + __uint_as_float(o[j] & 0xffff0000u);
+      ds += w0 * bt[2 * j] + w1 * bt[2 * j + 1];
+    }
+    *reinterpret_cast<uint4*>(fr + k) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  cs = wave_sum(cs);
+  ds = wave_sum(ds);
+  if (lane == 0) {
+    c[n] = cs;
+    d[n] = bias[n] + ds;
+  }
+}
+
+// (mean, rstd) of each row of x [rows, C] (two-pass, the row lives in registers); one wave per row.  Only for the
+// pre-LayerNorm output that enters layer 0; later statistics come out of the GEMM epilogues.
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, long rows, int C, float eps,
+                                                        float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * C;
+  float s = 0.f;
+  for (int k = lane * 8; k < C; k += 512) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += __uint_as_float(u[j] << 16) + __uint_as_float(u[j] & 0xffff0000u);
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int k = lane * 8; k < C; k += 512) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = __uint_as_float(u[j] << 16) - mu, b = __uint_as_float(u[j] & 0xffff0000u) - mu;
+      q += a * a + b * b;
+    }
+  }
+  const float var = wave_sum(q) / (float)C;
+  if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mu, rsqrtf(var + eps));
+}
+
+// (mean, rstd) from the per-64-column partial (sum, sum of squares) pairs a GE_RESID_ST epilogue wrote; fixed order.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, long rows, int np, int C,
+                                                             float eps, float* __restrict__ stats) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float2* pr = reinterpret_cast<const float2*>(part) + row * np;
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < np; ++i) {
+    const float2 v = pr[i];
+    s += v.x;
+    q += v.y;
+  }
+  const float mu = s / (float)C;
+  const float var = fmaxf(q / (float)C - mu * mu, 0.f);
+  *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mu, rsqrtf(var + eps));
+}
 
 int run_ln(const bf16_t* in, bf16_t* out, const float* g, const float* b, long rows, int C, long is, long os, float eps,
            hipStream_t st) {
@@ -460,6 +560,8 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
   TSPO_REQUIRE(n_frames >= 1, "clip_vit_forward: n_frames=%d", n_frames);
   const tspo_clip_config& c = w->cfg;
   if (int e = clip_check_cfg(c)) return e;
+  const bool no_fold = (pixel_dtype & 0x100) != 0;   // test hook: keep the stand-alone LayerNorm passes
+  pixel_dtype &= 0xff;
   TSPO_REQUIRE(w->patch_w && w->pos_emb && w->pre_g && w->pre_b && w->post_g && w->post_b && w->proj_w &&
                    (c.layers == 0 || w->layers),
                "clip_vit_forward: null weight pointer");
@@ -500,16 +602,34 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
   // 3. pre-LN (in place)
   if (int e = run_ln(b.x, b.x, w->pre_g, w->pre_b, M, C, C, C, c.ln_eps, st)) return e;
   prof.tick(PK_LN);
-  // 4. transformer blocks
+  // 4. transformer blocks.  Large batches: LayerNorm folded into the GEMMs (see ln_fold_kernel); otherwise stand-alone passes.
+  const bool fold = !no_fold && c.layers > 0 && tspo::gemm_bf16_is_big(M, C, C) && tspo::gemm_bf16_is_big(M, C, c.mlp);
+  if (fold) {
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, b.x, M, C, c.ln_eps, b.stats);
+    if (int e = tspo::check_launch("row_stats")) return e;
+    prof.tick(PK_LN);
+  }
   for (int l = 0; l < c.layers; ++l) {
     const tspo_clip_layer& L = w->layers[l];
     TSPO_REQUIRE(L.ln1_g && L.ln1_b && L.wqkv && L.bqkv && L.wo && L.bo && L.ln2_g && L.ln2_b && L.w1 && L.b1 && L.w2 && L.b2,
                  "clip_vit_forward: null pointer in layer %d", l);
-    if (int e = run_ln(b.x, b.h, L.ln1_g, L.ln1_b, M, C, C, C, c.ln_eps, st)) return e;
-    prof.tick(PK_LN);
     GemmArgs g{};
-    g.A = b.h; g.W = (const bf16_t*)L.wqkv; g.bias = L.bqkv; g.C = b.qkv; g.M = (int)M; g.N = 3 * C; g.K = C; g.P = 1;
-    if (int e = tspo::gemm_bf16(GE_BIAS, g, st)) return e;
+    if (fold) {
+      hipLaunchKernelGGL(ln_fold_kernel, dim3((3 * C + 3) / 4), dim3(256), 0, st, (const bf16_t*)L.wqkv, L.bqkv, L.ln1_g, L.ln1_b,
+                         3 * C, C, b.wqkv_f, b.cq, b.dq);
+      hipLaunchKernelGGL(ln_fold_kernel, dim3((c.mlp + 3) / 4), dim3(256), 0, st, (const bf16_t*)L.w1, L.b1, L.ln2_g, L.ln2_b,
+                         c.mlp, C, b.w1_f, b.c1, b.d1);
+      if (int e = tspo::check_launch("ln_fold")) return e;
+      prof.tick(PK_LN);
+      g.A = b.x; g.W = b.wqkv_f; g.bias = b.dq; g.lnc = b.cq; g.rstats = b.stats; g.C = b.qkv;
+      g.M = (int)M; g.N = 3 * C; g.K = C; g.P = 1;
+      if (int e = tspo::gemm_bf16(GE_BIAS_LN, g, st)) return e;
+    } else {
+      if (int e = run_ln(b.x, b.h, L.ln1_g, L.ln1_b, M, C, C, C, c.ln_eps, st)) return e;
+      prof.tick(PK_LN);
+      g.A = b.h; g.W = (const bf16_t*)L.wqkv; g.bias = L.bqkv; g.C = b.qkv; g.M = (int)M; g.N = 3 * C; g.K = C; g.P = 1;
+      if (int e = tspo::gemm_bf16(GE_BIAS, g, st)) return e;
+    }
     prof.tick(PK_GEMM);
     if (S == 257) hipLaunchKernelGGL(clip_attn_kernel<257>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     else hipLaunchKernelGGL(clip_attn_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
@@ -517,18 +637,37 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
     prof.tick(PK_ATTN);
     g = GemmArgs{};
     g.A = b.a; g.W = (const bf16_t*)L.wo; g.bias = L.bo; g.R = b.x; g.C = b.x; g.M = (int)M; g.N = C; g.K = C; g.P = 1;
-    if (int e = tspo::gemm_bf16(GE_RESID, g, st)) return e;
+    g.spart = b.spart;
+    if (int e = tspo::gemm_bf16(fold ? GE_RESID_ST : GE_RESID, g, st)) return e;
     prof.tick(PK_GEMM);
-    if (int e = run_ln(b.x, b.h, L.ln2_g, L.ln2_b, M, C, C, C, c.ln_eps, st)) return e;
-    prof.tick(PK_LN);
     g = GemmArgs{};
-    g.A = b.h; g.W = (const bf16_t*)L.w1; g.bias = L.b1; g.C = b.u; g.M = (int)M; g.N = c.mlp; g.K = C; g.P = 1;
-    if (int e = tspo::gemm_bf16(GE_GELU, g, st)) return e;
+    if (fold) {
+      hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, b.spart, M, C / 64, C,
+                         c.ln_eps, b.stats);
+      if (int e = tspo::check_launch("stats_finalize")) return e;
+      prof.tick(PK_LN);
+      g.A = b.x; g.W = b.w1_f; g.bias = b.d1; g.lnc = b.c1; g.rstats = b.stats; g.C = b.u;
+      g.M = (int)M; g.N = c.mlp; g.K = C; g.P = 1;
+      if (int e = tspo::gemm_bf16(GE_GELU_LN, g, st)) return e;
+    } else {
+      if (int e = run_ln(b.x, b.h, L.ln2_g, L.ln2_b, M, C, C, C, c.ln_eps, st)) return e;
+      prof.tick(PK_LN);
+      g.A = b.h; g.W = (const bf16_t*)L.w1; g.bias = L.b1; g.C = b.u; g.M = (int)M; g.N = c.mlp; g.K = C; g.P = 1;
+      if (int e = tspo::gemm_bf16(GE_GELU, g, st)) return e;
+    }
     prof.tick(PK_GEMM);
     g = GemmArgs{};
     g.A = b.u; g.W = (const bf16_t*)L.w2; g.bias = L.b2; g.R = b.x; g.C = b.x; g.M = (int)M; g.N = C; g.K = c.mlp; g.P = 1;
-    if (int e = tspo::gemm_bf16(GE_RESID, g, st)) return e;
+    g.spart = b.spart;
+    const bool next_needs_stats = fold && l + 1 < c.layers;   // the last block's output only feeds the CLS post-LN
+    if (int e = tspo::gemm_bf16(next_needs_stats ? GE_RESID_ST : GE_RESID, g, st)) return e;
     prof.tick(PK_GEMM);
+    if (next_needs_stats) {
+      hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, b.spart, M, C / 64, C,
+                         c.ln_eps, b.stats);
+      if (int e = tspo::check_launch("stats_finalize")) return e;
+      prof.tick(PK_LN);
+    }
   }
   // 5. CLS pool + post-LN + projection
   if (int e = run_ln(b.x, b.pooled, w->post_g, w->post_b, n_frames, C, (long)S * C, C, c.ln_eps, st)) return e;

@@ -7,6 +7,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
+__host__ __device__ constexpr bool epi_has_bias(int epi) {
+  return epi == GE_BIAS || epi == GE_GELU || epi == GE_RESID || epi == GE_BIAS_LN || epi == GE_GELU_LN || epi == GE_RESID_ST;
+}
+
 
 // ===========================================================================
 // GEMM  C[M,N] = A[M,K] * W[N,K]^T  (both operands K-contiguous, bf16)
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p3_kernel(GemmArgs g, int tiles
   const int l15 = lane & 15, q4 = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
   float* lbias = reinterpret_cast<float*>(lds + G2_NSTAGE * G2_STAGE);
-  if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID)
+  if (epi_has_bias(EPI))
     for (int i = tid; i < g.N; i += 512) lbias[i] = g.bias[i];
   const int nk = g.K / GT_BK;
   // Tile ownership per XCD (blockIdx % 8, observed placement - speed only).  The N tiles are split into `ngrp`
@@ -397,6 +401,24 @@ __device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int 
 template <int EPI, int MI>
 __device__ __forceinline__ void g3_epilogue_t(const GemmArgs& g, f32x4 (&acc)[4][MI], int m0, int n0, int rbase, int wn,
                                               int l15, int q4, const float* lbias) {
+  constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
+  constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
+  f32x4 lc[4];
+  if (LN) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + q4 * 4;
+      lc[ni] = *reinterpret_cast<const f32x4*>(g.lnc + (n < g.N ? n : 0));
+    }
+  }
+  float2 rst[MI];   // (mean, rstd) of this lane's MI rows: all loads in flight together (one latency, not MI)
+  if (LN) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + rbase + mi * 16 + l15;
+      rst[mi] = *reinterpret_cast<const float2*>(g.rstats + 2 * (size_t)(m < g.M ? m : g.M - 1));
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + rbase + mi * 16 + l15;
@@ -407,6 +429,12 @@ __device__ __forceinline__ void g3_epilogue_t(const GemmArgs& g, f32x4 (&acc)[4]
       prow = 1 + (m - f * g.P);
       orow = (size_t)f * (g.P + 1) + prow;
     }
+    float mu = 0.f, rs = 1.f;
+    if (LN) {
+      mu = rst[mi].x;
+      rs = rst[mi].y;
+    }
+    float ssum = 0.f, ssq = 0.f;
     uint2 pk[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -414,14 +442,15 @@ __device__ __forceinline__ void g3_epilogue_t(const GemmArgs& g, f32x4 (&acc)[4]
       f32x4 v = acc[ni][mi];
       acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const bool ok = m < g.M && n < g.N;
-      if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) v += *reinterpret_cast<const f32x4*>(lbias + (n < g.N ? n : 0));
-      if (EPI == GE_GELU) {
+      if (LN) v = (v - mu * lc[ni]) * rs;
+      if (epi_has_bias(EPI)) v += *reinterpret_cast<const f32x4*>(lbias + (n < g.N ? n : 0));
+      if (EPI == GE_GELU || EPI == GE_GELU_LN) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
       }
       const size_t o = orow * g.N + n;
       if (EPI == GE_PATCH && ok) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
-      if (EPI == GE_RESID && ok) {
+      if (RES && ok) {
         const uint2 rv = *reinterpret_cast<const uint2*>(g.R + o);
         v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
         v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
@@ -431,7 +460,22 @@ __device__ __forceinline__ void g3_epilogue_t(const GemmArgs& g, f32x4 (&acc)[4]
       } else {
         pk[ni].x = pack_bf16x2(v[0], v[1]);
         pk[ni].y = pack_bf16x2(v[2], v[3]);
+        if (EPI == GE_RESID_ST && ok) {   // statistics of the values as stored (bf16-rounded): what the next GEMM reads
+          const float r0 = __uint_as_float(pk[ni].x << 16), r1 = __uint_as_float(pk[ni].x & 0xffff0000u);
+          const float r2 = __uint_as_float(pk[ni].y << 16), r3 = __uint_as_float(pk[ni].y & 0xffff0000u);
+          ssum += (r0 + r1) + (r2 + r3);
+          ssq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+        }
       }
+    }
+    if (EPI == GE_RESID_ST) {   // the row's 64 columns of this wave live in the 4 lanes that share l15
+      ssum += __shfl_xor(ssum, 16, 64);
+      ssq += __shfl_xor(ssq, 16, 64);
+      ssum += __shfl_xor(ssum, 32, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      const int cslice = (n0 >> 6) + wn;
+      if (q4 == 0 && m < g.M && cslice * 64 < g.N)
+        *reinterpret_cast<float2*>(g.spart + ((size_t)m * (g.N >> 6) + cslice) * 2) = make_float2(ssum, ssq);
     }
     if (EPI != GE_F32) {
       // widen the stores: v_permlane16_swap exchanges the odd 16-lane rows of tile a with the even rows of tile
@@ -465,7 +509,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
   const int l15 = lane & 15, q4 = lane >> 4;
   const int wm = wid >> 2, wn = wid & 3;
   float* lbias = reinterpret_cast<float*>(lds + 2 * G3_STAGE);
-  if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID)
+  if (epi_has_bias(EPI))
     for (int i = tid; i < g.N; i += 512) lbias[i] = g.bias[i];
   const int nk = g.K / GT_BK;
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((size_t)g.M * g.K * 2), 0x00020000);
@@ -703,7 +747,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256_kernel(GemmArgs g, int til
   const int l15 = lane & 15, q4 = lane >> 4;
   const int wm = wid >> 2, wn = wid & 3;   // wm = wave-row = phase group (0: A leads, 1: B trails by one segment)
   float* lbias = reinterpret_cast<float*>(lds + 2 * G3_STAGE);
-  if (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID)
+  if (epi_has_bias(EPI))
     for (int i = tid; i < g.N; i += 512) lbias[i] = g.bias[i];
   const int nk = g.K / GT_BK;
   const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
@@ -942,7 +986,7 @@ int launch_gemm_w16(GemmArgs g, hipStream_t st) {
 // loads-only / A-loads-only, 1x = 2 with x N-groups, 2x = 2 loads-only with x N-groups.
 template <int EPI>
 int launch_gemm(GemmArgs g, hipStream_t st) {
-  const bool big = (long)g.M * g.N >= (long)256 * 256 * 256 && g.K >= 128 && g.N <= 4096;
+  const bool big = tspo::gemm_bf16_is_big(g.M, g.N, g.K);
   const int v = g.variant ? g.variant : (big ? 6 : 1);
   if (v == 1) return launch_gemm_v1<EPI>(g, st);
   if (v == 6) return launch_gemm_p256<EPI, 1, 6>(g, st);     // default: interleaved DMA issue + L2 prefetch of A 6 K-steps ahead
@@ -973,8 +1017,27 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
 
 }  // namespace
 
+bool tspo::gemm_bf16_is_big(long M, int N, int K) {
+  return M * N >= (long)256 * 256 * 256 && K >= 128 && N <= 4096;
+}
+
+namespace {
+// LayerNorm-folded epilogues exist only in the persistent 256x256 kernel
+template <int EPI>
+int launch_gemm_ln(GemmArgs g, hipStream_t st) {
+  if (!tspo::gemm_bf16_is_big(g.M, g.N, g.K) || g.N % 64)
+    return tspo::set_err(TSPO_EINVAL, "gemm: LayerNorm-folded epilogue %d needs the 256x256 kernel (M=%d N=%d K=%d)", EPI, g.M, g.N, g.K);
+  if (EPI == GE_RESID_ST ? !g.spart : !(g.lnc && g.rstats))
+    return tspo::set_err(TSPO_EINVAL, "gemm: epilogue %d without its statistics pointers", EPI);
+  return launch_gemm_p256<EPI, 1, 6>(g, st);
+}
+}  // namespace
+
 int tspo::gemm_bf16(int epi, const GemmArgs& g, hipStream_t st) {
   switch (epi) {
+    case GE_BIAS_LN: return launch_gemm_ln<GE_BIAS_LN>(g, st);
+    case GE_GELU_LN: return launch_gemm_ln<GE_GELU_LN>(g, st);
+    case GE_RESID_ST: return launch_gemm_ln<GE_RESID_ST>(g, st);
     case GE_BIAS: return launch_gemm<GE_BIAS>(g, st);
     case GE_GELU: return launch_gemm<GE_GELU>(g, st);
     case GE_RESID: return launch_gemm<GE_RESID>(g, st);

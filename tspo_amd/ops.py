@@ -280,8 +280,14 @@ class ClipVitWeights:
         return self._ws
 
 
-def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """pixels [N,3,H,W] (f32/bf16/f16 normalised, or uint8 raw) -> features f32 [N, proj]."""
+FOLD_LAYERNORM = True   # module default of clip_vit_forward(fold_layernorm=None); bench.py --no-ln-fold flips it for A/B runs
+
+
+def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torch.Tensor] = None,
+                     fold_layernorm: Optional[bool] = None) -> torch.Tensor:
+    """pixels [N,3,H,W] (f32/bf16/f16 normalised, or uint8 raw) -> features f32 [N, proj].
+    fold_layernorm=False keeps the stand-alone LayerNorm passes on large batches too (A/B test hook; small batches
+    never fold)."""
     _need_gpu(pixels)
     if pixels.dtype not in _PIX_DTYPES:
         raise TypeError(f"unsupported pixel dtype {pixels.dtype}")
@@ -292,7 +298,9 @@ def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torc
         raise ValueError(f"pixels must be [N,3,{cfg['image']},{cfg['image']}], got {tuple(px.shape)}")
     ws = w.workspace(N)
     feat = out if out is not None else torch.empty((N, cfg["proj"]), dtype=torch.float32, device=px.device)
-    check(_lib.lib().tspo_clip_vit_forward(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
+    fold = FOLD_LAYERNORM if fold_layernorm is None else fold_layernorm
+    dt = _PIX_DTYPES[px.dtype] | (0 if fold else 0x100)
+    check(_lib.lib().tspo_clip_vit_forward(C.byref(w.struct), _ptr(px), dt, N, _ptr(feat), _ptr(ws),
                                            ws.numel(), _stream()), "tspo_clip_vit_forward")
     return feat
 
@@ -305,7 +313,8 @@ def clip_vit_profile(w: ClipVitWeights, pixels: torch.Tensor) -> Dict[str, float
     ws = w.workspace(N)
     feat = torch.empty((N, w.cfg["proj"]), dtype=torch.float32, device=px.device)
     ms = (C.c_float * 6)()
-    check(_lib.lib().tspo_clip_vit_profile(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
+    dt = _PIX_DTYPES[px.dtype] | (0 if FOLD_LAYERNORM else 0x100)
+    check(_lib.lib().tspo_clip_vit_profile(C.byref(w.struct), _ptr(px), dt, N, _ptr(feat), _ptr(ws),
                                            ws.numel(), _stream(), ms), "tspo_clip_vit_profile")
     return {"gemm_ms": ms[0], "attn_ms": ms[1], "ln_ms": ms[2], "gather_ms": ms[3], "total_ms": ms[4],
             "gemm_launches": int(ms[5])}
