@@ -210,7 +210,10 @@ size_t tspo_clip_workspace_bytes(const tspo_clip_config* cfg, int n_frames);
  * pixels [N,3,image,image] of pixel_dtype: TSPO_F32/TSPO_BF16/TSPO_F16 =
  * already CLIP-normalised; TSPO_U8 = raw 0..255, (x/255-mean)/std fused into
  * the patch gather.  bf16 MFMA GEMMs with fp32 accumulation, bf16 activations.
- * feat f32 [N, proj].                                                       */
+ * feat f32 [N, proj].  For batches of >= 64 frames the per-layer LayerNorms
+ * are folded into the GEMMs around them (same maths, statistics taken from
+ * the bf16 residual stream as stored); OR-ing 0x100 into pixel_dtype keeps
+ * the stand-alone LayerNorm passes (A/B test hook).                         */
 int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
                           float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream);
 
