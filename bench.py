@@ -259,11 +259,12 @@ def main():
         # HBM-side bytes per GEMM launch: cannot be read from inside the process; taken from the committed PMC passes
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, tools/pmc_traffic.py) when they match this config
         traffic, tsrc = None, None
-        tpath = os.path.join(ROOT, "profiles", "r1_gemm_hbm_traffic_T1024.json")
+        tname = "r1_e_gemm_hbm_traffic_T1024.json" if ops.FOLD_LAYERNORM else "r1_gemm_hbm_traffic_T1024.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and B * T == 1024:
             try:
                 tj = json.load(open(tpath))
-                traffic, tsrc = tj["hbm_bytes_per_launch_avg"], "profiles/r1_gemm_hbm_traffic_T1024.json"
+                traffic, tsrc = tj["hbm_bytes_per_launch_avg"], "profiles/" + tname
             except Exception:
                 pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
