@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry-run aid: every rank uses cuda:0")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = torch default)")
+    ap.add_argument("--no-pruned", action="store_true", help="skip the extra (non-headline) run with the pruned last block")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: stand-alone LayerNorm passes instead of folding them into the GEMMs")
     a = ap.parse_args()
 
@@ -224,6 +225,18 @@ def main():
     frames = B * T * world * a.steps
     fps = frames / sec
     assert out["idx"].shape == (B, min(T, k)) and bool((out["idx"][:, 1:] > out["idx"][:, :-1]).all())
+
+    # ---- opt-in variant (NOT the headline): last transformer block evaluated for the class-token row only --------
+    # (its other 256 token rows have no consumer; identical features, 3.5 % fewer executed FLOPs; reported separately
+    # because `value` must execute the full model like the reference does)
+    pruned_fps = None
+    if not a.no_pruned:
+        ops.PRUNE_LAST_LAYER = True
+        psec = timed(score_step, a.steps, 1)
+        ops.PRUNE_LAST_LAYER = False
+        pruned_fps = frames / psec
+        assert bool((out["idx"][:, 1:] > out["idx"][:, :-1]).all())
+        score_step()   # restore the full-model outputs used by the checks below
 
     # ---- split: score + select only (features resident), SURVEY 8(d) ----------
     feats_res = scorer.encode(pixels)
@@ -295,6 +308,10 @@ def main():
             "rollouts_config": None if rollouts is None else {"workload": "configs[2] policy step (reward LLM excluded)",
                                                               "B": 4, "T": 512, "G": 8, "k": 16},
             "encode_tflops": round((gemm_flops_per_frame(c) + attn_flops_per_frame(c)) * fps / 1e12, 1),
+            "optional_pruned_last_block": None if pruned_fps is None else {
+                "frames_scored_per_s": round(pruned_fps, 2),
+                "note": "opt-in ops.clip_vit_forward(prune_last_layer=True): last block for the class-token row only "
+                        "(same features); not used for `value`"},
             "split_ms": {"encode": round(sec / a.steps * 1e3 - sel_sec * 1e3, 3), "score_select": round(sel_sec * 1e3, 3)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -405,6 +405,13 @@ def test_clip_vit_forward_70_frames_production_kernels():
     d = np.abs(feats[True] - feats[False]).max() / scale
     print(f"[clip_l14 x70] folded vs stand-alone LayerNorm: max|diff|/max|ref| {d:.4f}")
     assert d < 3e-2
+    # opt-in pruning of the last block to the class-token row: same features (only the small-GEMM path differs)
+    for fold in (True, False):
+        fp = ops.clip_vit_forward(W, G_(u8), fold_layernorm=fold, prune_last_layer=True).cpu().numpy()
+        dp = np.abs(fp - feats[fold]).max() / scale
+        err = np.abs(fp - ref).max() / scale
+        print(f"[clip_l14 x70, fold={fold}] pruned last block: max|diff to full|/max|ref| {dp:.5f}, err vs oracle {err:.4f}")
+        assert dp < 5e-3 and err < 3e-2
 
 
 def _clip_ref_bf16_weights(cfg, n):
@@ -440,6 +447,10 @@ def test_clip_vit_forward(golden, case):
     # frames are independent: frame 1 alone == frame 1 in the batch (bitwise, same kernels / same order)
     f1 = ops.clip_vit_forward(W, G_(px[1:2])).cpu().numpy()
     np.testing.assert_array_equal(f1[0], feat[1])
+    # opt-in: last block evaluated for the class-token row only -> same features against the same golden
+    fp = ops.clip_vit_forward(W, G_(px), prune_last_layer=True).cpu().numpy()
+    assert np.abs(fp - feat).max() / scale < 5e-3
+    assert np.abs(fp - gold).max() / scale < 3e-2
 
 
 def test_clip_scores():

@@ -422,6 +422,69 @@ struct Prof {
 };
 
 // ---------------------------------------------------------------------------
+// Attention of the class-token query only (opt-in pruning of the LAST block: its other 256 token rows have no consumer,
+// get_image_features pools row 0).  One wave per (frame, head): scores of q_0 against all S keys (lane j owns keys
+// j, j+64, ...), softmax across the wave, then lane d accumulates sum_j p_j V[j][d] with p broadcast through LDS.
+__global__ __launch_bounds__(64) void clip_attn_cls_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
+                                                           int C, float scale) {
+  __shared__ float pl[AT_KEYS];
+  const int lane = threadIdx.x, h = blockIdx.x;
+  const size_t f = blockIdx.y, ld = (size_t)3 * C;
+  const bf16_t* base = qkv + f * S * ld + (size_t)h * 64;
+  float q[64];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(base + c * 8);   // row 0, q columns (wave-uniform address)
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      q[c * 8 + 2 * j] = __uint_as_float(u[j] << 16);
+      q[c * 8 + 2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+    }
+  }
+  float sc[(AT_KEYS + 63) / 64];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < (AT_KEYS + 63) / 64; ++i) {
+    const int key = lane + 64 * i;
+    float d = -INFINITY;
+    if (key < S) {
+      const bf16_t* kr = base + (size_t)key * ld + C;
+      d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(kr + c * 8);
+        const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          d += q[c * 8 + 2 * j] * __uint_as_float(u[j] << 16) + q[c * 8 + 2 * j + 1] * __uint_as_float(u[j] & 0xffff0000u);
+      }
+      d *= scale;
+    }
+    sc[i] = d;
+    mx = fmaxf(mx, d);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < (AT_KEYS + 63) / 64; ++i) {
+    const int key = lane + 64 * i;
+    const float p = key < S ? __expf(sc[i] - mx) : 0.f;
+    sum += p;
+    if (key < AT_KEYS) pl[key] = p;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float o = 0.f;
+  const bf16_t* vb = base + 2 * C + lane;
+  for (int key = 0; key < S; ++key) o += pl[key] * bf16_to_f32(vb[(size_t)key * ld]);
+  o /= sum;
+  // bf16 store of this head's 64 outputs of frame f (compact [n_frames, C] layout)
+  const uint32_t pk = pack_bf16x2(o, __shfl_down(o, 1, 64));
+  if ((lane & 1) == 0) *reinterpret_cast<uint32_t*>(out + f * (size_t)C + (size_t)h * 64 + lane) = pk;
+}
+
+// ---------------------------------------------------------------------------
 // LayerNorm folded into the GEMMs around it (large batches).  LN(x) W^T = rstd * (x W'^T - mu * c) + (b + W beta) with
 // W' = gamma o W and c[n] = sum_k W'[n,k]: the consumer GEMM reads the raw residual stream and its epilogue applies the
 // per-row (mu, rstd); those come from partial sums the producer GEMM's residual epilogue writes (GE_RESID_ST), so the
@@ -561,6 +624,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
   const tspo_clip_config& c = w->cfg;
   if (int e = clip_check_cfg(c)) return e;
   const bool no_fold = (pixel_dtype & 0x100) != 0;   // test hook: keep the stand-alone LayerNorm passes
+  const bool prune = (pixel_dtype & 0x200) != 0;     // opt-in: last block evaluated for the class-token row only
   pixel_dtype &= 0xff;
   TSPO_REQUIRE(w->patch_w && w->pos_emb && w->pre_g && w->pre_b && w->post_g && w->post_b && w->proj_w &&
                    (c.layers == 0 || w->layers),
@@ -609,6 +673,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
     if (int e = tspo::check_launch("row_stats")) return e;
     prof.tick(PK_LN);
   }
+  bool pooled_done = false;
   for (int l = 0; l < c.layers; ++l) {
     const tspo_clip_layer& L = w->layers[l];
     TSPO_REQUIRE(L.ln1_g && L.ln1_b && L.wqkv && L.bqkv && L.wo && L.bo && L.ln2_g && L.ln2_b && L.w1 && L.b1 && L.w2 && L.b2,
@@ -631,6 +696,35 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       if (int e = tspo::gemm_bf16(GE_BIAS, g, st)) return e;
     }
     prof.tick(PK_GEMM);
+    if (prune && l == c.layers - 1) {
+      // Only row 0 of every frame leaves the encoder (post-LN + projection of the class token), so the rest of this
+      // block runs on the compact [n_frames, C] class-token rows: attention of q_0, out-proj, LN2, MLP.
+      bf16_t* xc = b.h + (size_t)n_frames * C;   // class-token residual rows (b.h is free here); LN2 output goes to b.h
+      hipLaunchKernelGGL(clip_attn_cls_kernel, dim3(c.heads, n_frames), dim3(64), 0, st, b.qkv, b.a, S, C, 0.125f);
+      if (int e = tspo::check_launch("clip_attn_cls")) return e;
+      prof.tick(PK_ATTN);
+      hipError_t ce = hipMemcpy2DAsync(xc, (size_t)C * 2, b.x, (size_t)S * C * 2, (size_t)C * 2, n_frames,
+                                       hipMemcpyDeviceToDevice, st);
+      if (ce != hipSuccess) return tspo::set_err(TSPO_ELAUNCH, "clip_vit_forward: class-row gather: %s", hipGetErrorString(ce));
+      g = GemmArgs{};
+      g.A = b.a; g.W = (const bf16_t*)L.wo; g.bias = L.bo; g.R = xc; g.C = xc; g.M = n_frames; g.N = C; g.K = C; g.P = 1;
+      if (int e = tspo::gemm_bf16(GE_RESID, g, st)) return e;
+      prof.tick(PK_GEMM);
+      if (int e = run_ln(xc, b.h, L.ln2_g, L.ln2_b, n_frames, C, C, C, c.ln_eps, st)) return e;
+      prof.tick(PK_LN);
+      g = GemmArgs{};
+      g.A = b.h; g.W = (const bf16_t*)L.w1; g.bias = L.b1; g.C = b.u; g.M = n_frames; g.N = c.mlp; g.K = C; g.P = 1;
+      if (int e = tspo::gemm_bf16(GE_GELU, g, st)) return e;
+      prof.tick(PK_GEMM);
+      g = GemmArgs{};
+      g.A = b.u; g.W = (const bf16_t*)L.w2; g.bias = L.b2; g.R = xc; g.C = xc; g.M = n_frames; g.N = C; g.K = c.mlp; g.P = 1;
+      if (int e = tspo::gemm_bf16(GE_RESID, g, st)) return e;
+      prof.tick(PK_GEMM);
+      if (int e = run_ln(xc, b.pooled, w->post_g, w->post_b, n_frames, C, C, C, c.ln_eps, st)) return e;
+      prof.tick(PK_LN);
+      pooled_done = true;
+      break;
+    }
     if (S == 257) hipLaunchKernelGGL(clip_attn_kernel<257>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     else hipLaunchKernelGGL(clip_attn_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     if (int e = tspo::check_launch("clip_attn")) return e;
@@ -670,8 +764,10 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
     }
   }
   // 5. CLS pool + post-LN + projection
-  if (int e = run_ln(b.x, b.pooled, w->post_g, w->post_b, n_frames, C, (long)S * C, C, c.ln_eps, st)) return e;
-  prof.tick(PK_LN);
+  if (!pooled_done) {
+    if (int e = run_ln(b.x, b.pooled, w->post_g, w->post_b, n_frames, C, (long)S * C, C, c.ln_eps, st)) return e;
+    prof.tick(PK_LN);
+  }
   {
     GemmArgs g{};
     g.A = b.pooled; g.W = (const bf16_t*)w->proj_w; g.C = feat; g.M = n_frames; g.N = c.proj; g.K = C; g.P = 1;

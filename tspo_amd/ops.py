@@ -283,11 +283,16 @@ class ClipVitWeights:
 FOLD_LAYERNORM = True   # module default of clip_vit_forward(fold_layernorm=None); bench.py --no-ln-fold flips it for A/B runs
 
 
+PRUNE_LAST_LAYER = False   # module default of clip_vit_forward(prune_last_layer=None)
+
+
 def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torch.Tensor] = None,
-                     fold_layernorm: Optional[bool] = None) -> torch.Tensor:
+                     fold_layernorm: Optional[bool] = None, prune_last_layer: Optional[bool] = None) -> torch.Tensor:
     """pixels [N,3,H,W] (f32/bf16/f16 normalised, or uint8 raw) -> features f32 [N, proj].
     fold_layernorm=False keeps the stand-alone LayerNorm passes on large batches too (A/B test hook; small batches
-    never fold)."""
+    never fold).  prune_last_layer=True (opt-in, off by default) evaluates the last transformer block for the class-token
+    row only - the other token rows of that block have no consumer (get_image_features pools row 0), so the features are
+    the same; it is off by default so that the default path executes the full model like the reference does."""
     _need_gpu(pixels)
     if pixels.dtype not in _PIX_DTYPES:
         raise TypeError(f"unsupported pixel dtype {pixels.dtype}")
@@ -299,7 +304,8 @@ def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torc
     ws = w.workspace(N)
     feat = out if out is not None else torch.empty((N, cfg["proj"]), dtype=torch.float32, device=px.device)
     fold = FOLD_LAYERNORM if fold_layernorm is None else fold_layernorm
-    dt = _PIX_DTYPES[px.dtype] | (0 if fold else 0x100)
+    prune = PRUNE_LAST_LAYER if prune_last_layer is None else prune_last_layer
+    dt = _PIX_DTYPES[px.dtype] | (0 if fold else 0x100) | (0x200 if prune else 0)
     check(_lib.lib().tspo_clip_vit_forward(C.byref(w.struct), _ptr(px), dt, N, _ptr(feat), _ptr(ws),
                                            ws.numel(), _stream()), "tspo_clip_vit_forward")
     return feat
