@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__
   }
 }
 
-// (mean, rstd) of each row of x [rows, C] (two-pass, the row lives in registers); one wave per row.  Only for the
+// (rstd, -mean*rstd) of each row of x [rows, C] (two-pass, the row lives in registers); one wave per row.  Only for the
 // pre-LayerNorm output that enters layer 0; later statistics come out of the GEMM epilogues.
 __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, long rows, int C, float eps,
                                                         float* __restrict__ stats) {
@@ -553,10 +553,11 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict
     }
   }
   const float var = wave_sum(q) / (float)C;
-  if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mu, rsqrtf(var + eps));
+  const float rstd = rsqrtf(var + eps);
+  if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(rstd, -mu * rstd);
 }
 
-// (mean, rstd) from the per-64-column partial (sum, sum of squares) pairs a GE_RESID_ST epilogue wrote; fixed order.
+// (rstd, -mean*rstd) from the per-64-column partial (sum, sum of squares) pairs a GE_RESID_ST epilogue wrote; fixed order.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, long rows, int np, int C,
                                                              float eps, float* __restrict__ stats) {
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
@@ -570,7 +571,8 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
   }
   const float mu = s / (float)C;
   const float var = fmaxf(q / (float)C - mu * mu, 0.f);
-  *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mu, rsqrtf(var + eps));
+  const float rstd = rsqrtf(var + eps);
+  *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(rstd, -mu * rstd);
 }
 
 int run_ln(const bf16_t* in, bf16_t* out, const float* g, const float* b, long rows, int C, long is, long os, float eps,

@@ -431,8 +431,8 @@ __device__ __forceinline__ void g3_epilogue_t(const GemmArgs& g, f32x4 (&acc)[4]
     }
     float mu = 0.f, rs = 1.f;
     if (LN) {
-      mu = rst[mi].x;
-      rs = rst[mi].y;
+      rs = rst[mi].x;   // rstd
+      mu = rst[mi].y;   // -mean * rstd
     }
     float ssum = 0.f, ssq = 0.f;
     uint2 pk[4];
@@ -442,8 +442,13 @@ __device__ __forceinline__ void g3_epilogue_t(const GemmArgs& g, f32x4 (&acc)[4]
       f32x4 v = acc[ni][mi];
       acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const bool ok = m < g.M && n < g.N;
-      if (LN) v = (v - mu * lc[ni]) * rs;
-      if (epi_has_bias(EPI)) v += *reinterpret_cast<const f32x4*>(lbias + (n < g.N ? n : 0));
+      if (LN) {   // rstats holds (rstd, -mean*rstd): y = acc*rstd + (-mean*rstd)*c[n] + d[n], two FMAs per value
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(lbias + (n < g.N ? n : 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], rs, fmaf(mu, lc[ni][r], dv[r]));
+      } else if (epi_has_bias(EPI)) {
+        v += *reinterpret_cast<const f32x4*>(lbias + (n < g.N ? n : 0));
+      }
       if (EPI == GE_GELU || EPI == GE_GELU_LN) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
