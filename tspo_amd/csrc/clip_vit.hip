@@ -560,19 +560,28 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict
 // (rstd, -mean*rstd) from the per-64-column partial (sum, sum of squares) pairs a GE_RESID_ST epilogue wrote; fixed order.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, long rows, int np, int C,
                                                              float eps, float* __restrict__ stats) {
-  const long row = (long)blockIdx.x * 256 + threadIdx.x;
-  if (row >= rows) return;
-  const float2* pr = reinterpret_cast<const float2*>(part) + row * np;
+  // 16 lanes per row: lane i sums partials i, i+16, ... (coalesced 128-byte reads), then a fixed xor tree
+  const int sub = threadIdx.x & 15;
+  const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < rows;
+  const float2* pr = reinterpret_cast<const float2*>(part) + (live ? row : 0) * np;
   float s = 0.f, q = 0.f;
-  for (int i = 0; i < np; ++i) {
+  for (int i = sub; i < np; i += 16) {
     const float2 v = pr[i];
     s += v.x;
     q += v.y;
   }
-  const float mu = s / (float)C;
-  const float var = fmaxf(q / (float)C - mu * mu, 0.f);
-  const float rstd = rsqrtf(var + eps);
-  *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(rstd, -mu * rstd);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 16);
+    q += __shfl_xor(q, o, 16);
+  }
+  if (live && sub == 0) {
+    const float mu = s / (float)C;
+    const float var = fmaxf(q / (float)C - mu * mu, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(rstd, -mu * rstd);
+  }
 }
 
 int run_ln(const bf16_t* in, bf16_t* out, const float* g, const float* b, long rows, int C, long is, long os, float eps,
@@ -738,7 +747,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
     prof.tick(PK_GEMM);
     g = GemmArgs{};
     if (fold) {
-      hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, b.spart, M, C / 64, C,
+      hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, b.spart, M, C / 64, C,
                          c.ln_eps, b.stats);
       if (int e = tspo::check_launch("stats_finalize")) return e;
       prof.tick(PK_LN);
@@ -759,7 +768,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
     if (int e = tspo::gemm_bf16(next_needs_stats ? GE_RESID_ST : GE_RESID, g, st)) return e;
     prof.tick(PK_GEMM);
     if (next_needs_stats) {
-      hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, b.spart, M, C / 64, C,
+      hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, b.spart, M, C / 64, C,
                          c.ln_eps, b.stats);
       if (int e = tspo::check_launch("stats_finalize")) return e;
       prof.tick(PK_LN);
