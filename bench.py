@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry-run aid: every rank uses cuda:0")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = torch default)")
+    ap.add_argument("--rollout-cfg", default="4,512,8,16", help="B,T,G,k of the policy step (configs[2]: 4,512,8,16; configs[4] stress: 1,4096,16,16)")
     ap.add_argument("--no-pruned", action="store_true", help="skip the extra (non-headline) run with the pruned last block")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: stand-alone LayerNorm passes instead of folding them into the GEMMs")
     a = ap.parse_args()
@@ -251,7 +252,8 @@ def main():
     # ---- rollouts / s (policy side of one TSPO step, configs[2]) --------------
     rollouts = None
     if not a.no_rollouts:
-        Bt, Tt, G, kt, tau = 4, 512, 8, 16, 0.025
+        Bt, Tt, G, kt = (int(v) for v in a.rollout_cfg.split(","))
+        tau = 0.025
         gen = torch.Generator(device=dev).manual_seed(99 + rank)
         feats = torch.randn(Bt, Tt, 768, generator=gen, device=dev)
         ttxt = torch.randn(Bt, 1, 768, generator=gen, device=dev)
@@ -305,8 +307,8 @@ def main():
                        "pixels": a.pixels, "weights": "random-init CLIP-L/14 + selector", "parallelism": f"dp{world}",
                        "layernorm": "stand-alone" if a.no_ln_fold else "folded into GEMMs"},
             "rollouts_per_s": None if rollouts is None else round(rollouts, 1),
-            "rollouts_config": None if rollouts is None else {"workload": "configs[2] policy step (reward LLM excluded)",
-                                                              "B": 4, "T": 512, "G": 8, "k": 16},
+            "rollouts_config": None if rollouts is None else {"workload": "policy step (reward LLM excluded); default = configs[2]",
+                                                              "B": Bt, "T": Tt, "G": G, "k": kt},
             "encode_tflops": round((gemm_flops_per_frame(c) + attn_flops_per_frame(c)) * fps / 1e12, 1),
             "optional_pruned_last_block": None if pruned_fps is None else {
                 "frames_scored_per_s": round(pruned_fps, 2),
