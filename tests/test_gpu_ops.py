@@ -313,6 +313,26 @@ def test_selector_fwd_bwd_vs_oracle_autograd(case):
             np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-5 * max(np.abs(ref).max(), 1e-12))
 
 
+def test_selector_fwd_bwd_bitwise_repeatable():
+    """Race screen for the LDS-DMA ring GEMMs / MFMA banded attention: the same inputs must give bit-identical scores and
+    gradients every time (fixed-order split reductions, counted vmcnt waits) at the policy-step shape of the bench."""
+    B, T, D, H, M, w, tau = 4, 512, 768, 8, 1, 12, 0.025
+    img, txt = G_(synth.normal((B, T, D), 2100)), G_(synth.normal((B, M, D), 2101))
+    clip, ds = G_(synth.normal((B, T), 2102, 0.1)), G_(synth.normal((B, T), 2103, 0.01))
+    flat = flat_from_state(synth.selector_state(D, seed=9, std=0.02, bias_std=0.01), D)
+    ref_s = ref_g = None
+    for it in range(25):
+        s, _, ws = ops.selector_forward(flat, img, txt, clip, H, w, tau, want_attn=False)
+        g = torch.zeros_like(flat)
+        ops.selector_backward(flat, g, img, txt, ds, H, w, tau, ws)
+        if ref_s is None:
+            ref_s, ref_g = s.clone(), g.clone()
+            assert torch.isfinite(ref_g).all() and ref_g.abs().max() > 0
+        else:
+            assert torch.equal(s, ref_s), f"scores differ on repetition {it}"
+            assert torch.equal(g, ref_g), f"gradients differ on repetition {it}"
+
+
 def test_selector_backward_batched_sums():
     """grads of a batch == sum of per-video grads (what the DP all-reduce relies on)."""
     B, T, D, H, M, w, tau = 3, 96, 64, 8, 1, 12, 0.025
@@ -402,6 +422,11 @@ def test_clip_vit_forward_70_frames_production_kernels():
         print(f"\n[clip_l14 x70, fold_layernorm={fold}] max|err|/max|ref| {err:.4f}, min cos {cos.min():.6f}")
         assert err < 3e-2 and cos.min() > 0.999
         feats[fold] = feat
+    # race screen for the persistent GEMM ring + LayerNorm-fold epilogues: repeated encodes are bit-identical
+    for fold in (True, False):
+        for _ in range(3):
+            again = ops.clip_vit_forward(W, G_(u8), fold_layernorm=fold).cpu().numpy()
+            np.testing.assert_array_equal(again, feats[fold])
     d = np.abs(feats[True] - feats[False]).max() / scale
     print(f"[clip_l14 x70] folded vs stand-alone LayerNorm: max|diff|/max|ref| {d:.4f}")
     assert d < 3e-2
