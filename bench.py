@@ -136,7 +136,16 @@ def cpu_baseline(T, k, budget_s=20.0):
         O.topk_sorted(s, k)
         tsel = time.perf_counter() - t0
     per_frame = tn / n + tsel / T
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(1.0 / per_frame, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "host_logical_cpus": os.cpu_count(),
             "sample": f"oracle (torch-CPU fp32): CLIP-L/14 on {n} frames in {tn:.2f}s + selector/top-k at T={T} in "
                       f"{tsel * 1e3:.1f}ms, {cores} threads"}
 
