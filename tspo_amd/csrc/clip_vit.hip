@@ -557,30 +557,41 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict
   if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(rstd, -mu * rstd);
 }
 
-// (rstd, -mean*rstd) from the per-64-column partial (sum, sum of squares) pairs a GE_RESID_ST epilogue wrote; fixed order.
+// (rstd, -mean*rstd) from the per-64-column slice statistics (mean, centred sum of squares M2) a GE_RESID_ST epilogue
+// wrote.  Slices are merged pairwise with Chan's formula (n = na + nb, d = mb - ma, mean = ma + d*nb/n,
+// M2 = M2a + M2b + d*d*na*nb/n) in a fixed xor tree over 16 lanes per row -> deterministic and as robust as two passes.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, long rows, int np, int C,
                                                              float eps, float* __restrict__ stats) {
-  // 16 lanes per row: lane i sums partials i, i+16, ... (coalesced 128-byte reads), then a fixed xor tree
   const int sub = threadIdx.x & 15;
   const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
   const bool live = row < rows;
   const float2* pr = reinterpret_cast<const float2*>(part) + (live ? row : 0) * np;
-  float s = 0.f, q = 0.f;
-  for (int i = sub; i < np; i += 16) {
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int i = sub; i < np; i += 16) {   // (coalesced 128-byte reads per row)
     const float2 v = pr[i];
-    s += v.x;
-    q += v.y;
+    const float nn = n + 64.f, d = v.x - mean;
+    mean += d * (64.f / nn);
+    m2 += v.y + d * d * (n * 64.f / nn);
+    n = nn;
   }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o, 16);
-    q += __shfl_xor(q, o, 16);
+    const float nb = __shfl_xor(n, o, 16), mb = __shfl_xor(mean, o, 16), qb = __shfl_xor(m2, o, 16);
+    const float nn = n + nb;
+    if (nn > 0.f) {
+      // symmetric in (a, b): both partners compute the same merged triple
+      const float d = mb - mean;
+      const float wgt = nb / nn;
+      const float merged_mean = (n * mean + nb * mb) / nn;
+      m2 = m2 + qb + d * d * (n * wgt);
+      mean = merged_mean;
+      n = nn;
+    }
   }
   if (live && sub == 0) {
-    const float mu = s / (float)C;
-    const float var = fmaxf(q / (float)C - mu * mu, 0.f);
+    const float var = fmaxf(m2 / (float)C, 0.f);
     const float rstd = rsqrtf(var + eps);
-    *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(rstd, -mu * rstd);
+    *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(rstd, -mean * rstd);
   }
 }
 

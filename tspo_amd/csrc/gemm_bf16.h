@@ -6,8 +6,8 @@ typedef uint16_t bf16_t;
 
 // GE_BIAS_LN / GE_GELU_LN: the A operand is the RAW residual stream x and W carries the LayerNorm scale (W' = gamma o W);
 // the epilogue applies the per-row statistics: y = rstd_m * acc - (mu_m * rstd_m) * lnc[n] + bias[n] with lnc[n] = sum_k W'[n,k]
-// and bias = the folded bias (b + W beta).  GE_RESID_ST: GE_RESID that also writes per-row partial (sum, sum of squares) of
-// the bf16 values it stores, one pair per 64-column slice: spart[m][N/64][2]  (LayerNorm folded into the GEMMs around it).
+// and bias = the folded bias (b + W beta).  GE_RESID_ST: GE_RESID that also writes, per row and 64-column slice, the (mean, centred sum
+// of squares) of the bf16 values it stores: spart[m][N/64][2]  (LayerNorm folded into the GEMMs around it).
 enum { GE_BIAS = 0, GE_GELU = 1, GE_RESID = 2, GE_F32 = 3, GE_PATCH = 4, GE_BIAS_LN = 5, GE_GELU_LN = 6, GE_RESID_ST = 7 };
 
 struct GemmArgs {
@@ -15,7 +15,7 @@ struct GemmArgs {
   const float* pos;  // GE_PATCH: pos_emb [S, N]
   const float* lnc;     // GE_*_LN: column sums of the folded weight [N]
   const float* rstats;  // GE_*_LN: (rstd, -mean*rstd) per row of A [M][2]
-  float* spart;         // GE_RESID_ST: partial row statistics out [M][N/64][2]
+  float* spart;         // GE_RESID_ST: per-slice (mean, M2) row statistics out [M][N/64][2]
   int M, N, K, tilesN, nwg, P;  // P: patches per frame (GE_PATCH row remap); P < 0 = ablation hooks (tests only)
   int variant;                  // 0 = auto; 1 = 128x128 2-stage; 2 = persistent 256x128 ring; 6 = persistent 256x256
   int ngrp;                     // 0 = auto N-group count per XCD

@@ -469,18 +469,26 @@ __device__ __forceinline__ void g3_epilogue_t(const GemmArgs& g, f32x4 (&acc)[4]
           const float r0 = __uint_as_float(pk[ni].x << 16), r1 = __uint_as_float(pk[ni].x & 0xffff0000u);
           const float r2 = __uint_as_float(pk[ni].y << 16), r3 = __uint_as_float(pk[ni].y & 0xffff0000u);
           ssum += (r0 + r1) + (r2 + r3);
-          ssq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
         }
       }
     }
     if (EPI == GE_RESID_ST) {   // the row's 64 columns of this wave live in the 4 lanes that share l15
+      // per-slice (mean, centred sum of squares): two passes over the 16 stored values of this lane, so the later
+      // combination of the N/64 slices (Chan et al.) is as robust as a two-pass LayerNorm
       ssum += __shfl_xor(ssum, 16, 64);
-      ssq += __shfl_xor(ssq, 16, 64);
       ssum += __shfl_xor(ssum, 32, 64);
+      const float smean = ssum * (1.0f / 64.0f);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const float d0 = __uint_as_float(pk[ni].x << 16) - smean, d1 = __uint_as_float(pk[ni].x & 0xffff0000u) - smean;
+        const float d2 = __uint_as_float(pk[ni].y << 16) - smean, d3 = __uint_as_float(pk[ni].y & 0xffff0000u) - smean;
+        ssq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+      ssq += __shfl_xor(ssq, 16, 64);
       ssq += __shfl_xor(ssq, 32, 64);
       const int cslice = (n0 >> 6) + wn;
       if (q4 == 0 && m < g.M && cslice * 64 < g.N)
-        *reinterpret_cast<float2*>(g.spart + ((size_t)m * (g.N >> 6) + cslice) * 2) = make_float2(ssum, ssq);
+        *reinterpret_cast<float2*>(g.spart + ((size_t)m * (g.N >> 6) + cslice) * 2) = make_float2(smean, ssq);
     }
     if (EPI != GE_F32) {
       // widen the stores: v_permlane16_swap exchanges the odd 16-lane rows of tile a with the even rows of tile
