@@ -9,7 +9,9 @@
 
 namespace {
 
-__device__ __forceinline__ uint8_t clip8(long long v) {
+// 32-bit accumulation like Pillow's ImagingResample (INT32 ss = 1 << 21; ss += pixel * k): |sum| <= 255 * sum|k| with
+// sum|k| < 1.4 * 2^22 for the antialiased bicubic, i.e. < 2^31.
+__device__ __forceinline__ uint8_t clip8(int v) {
   v >>= 22;
   return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
@@ -27,19 +29,19 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restri
     const int xmin = bound[2 * x], xn = bound[2 * x + 1];
     const int* k = coef + (size_t)x * ksize;
     const int y = ylo + yy;
-    long long a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
     if (layout == 0) {  // [T,H,W,3]
       const uint8_t* p = in + ((t * H + y) * (size_t)W + xmin) * 3;
       for (int i = 0; i < xn; ++i) {
-        const long long w = k[i];
-        a0 += w * p[3 * i]; a1 += w * p[3 * i + 1]; a2 += w * p[3 * i + 2];
+        const int w = k[i];
+        a0 += w * (int)p[3 * i]; a1 += w * (int)p[3 * i + 1]; a2 += w * (int)p[3 * i + 2];
       }
     } else {  // [T,3,H,W]
       const uint8_t* p = in + ((t * 3) * (size_t)H + y) * W + xmin;
       const size_t cs = (size_t)H * W;
       for (int i = 0; i < xn; ++i) {
-        const long long w = k[i];
-        a0 += w * p[i]; a1 += w * p[cs + i]; a2 += w * p[2 * cs + i];
+        const int w = k[i];
+        a0 += w * (int)p[i]; a1 += w * (int)p[cs + i]; a2 += w * (int)p[2 * cs + i];
       }
     }
     const size_t o = ((t * 3) * (size_t)nrows + yy) * ow + x;
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* __restri
     const int ymin = bound[2 * y] - ylo, yn = bound[2 * y + 1];
     const int* k = coef + (size_t)y * ksize;
     const uint8_t* p = tmp + (tc * nrows + ymin) * (size_t)ow + x;
-    long long a = 1 << 21;
-    for (int i = 0; i < yn; ++i) a += (long long)k[i] * p[(size_t)i * ow];
+    int a = 1 << 21;
+    for (int i = 0; i < yn; ++i) a += k[i] * (int)p[(size_t)i * ow];
     out[id] = clip8(a);
   }
 }
