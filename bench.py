@@ -259,7 +259,7 @@ def main():
     assert torch.equal(out["idx2"], out["idx"])
 
     # ---- rollouts / s (policy side of one TSPO step, configs[2]) --------------
-    rollouts = None
+    rollouts = rollouts_x3 = None
     if not a.no_rollouts:
         Bt, Tt, G, kt = (int(v) for v in a.rollout_cfg.split(","))
         tau = 0.025
@@ -271,6 +271,10 @@ def main():
         trainer = PolicyTrainer(flat.clone())
         rsec = timed(lambda: trainer.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 20), 3)
         rollouts = Bt * G * world * max(a.steps, 20) / rsec
+        # opt-in split-precision selector GEMMs (NOT the headline number): see DESIGN.md, TSPO_SEL_BF16X3
+        trainer_x3 = PolicyTrainer(flat.clone(), gemm_precision="bf16x3")
+        xsec = timed(lambda: trainer_x3.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 20), 3)
+        rollouts_x3 = Bt * G * world * max(a.steps, 20) / xsec
 
     # ---- roofline of the dominant kernel (bf16 MFMA GEMM), live HIP-event timing --------------------------
     roof = None
@@ -316,6 +320,10 @@ def main():
                        "pixels": a.pixels, "weights": "random-init CLIP-L/14 + selector", "parallelism": f"dp{world}",
                        "layernorm": "stand-alone" if a.no_ln_fold else "folded into GEMMs"},
             "rollouts_per_s": None if rollouts is None else round(rollouts, 1),
+            "optional_rollouts_per_s_bf16x3": None if rollouts_x3 is None else {
+                "rollouts_per_s": round(rollouts_x3, 1),
+                "note": "opt-in PolicyTrainer(gemm_precision='bf16x3'): selector GEMMs as hi/lo bf16 splits on the bf16 MFMA "
+                        "(~1e-5 relative error vs exact fp32); not used for `rollouts_per_s`"},
             "rollouts_config": None if rollouts is None else {"workload": "policy step (reward LLM excluded); default = configs[2]",
                                                               "B": Bt, "T": Tt, "G": G, "k": kt},
             "encode_tflops": round((gemm_flops_per_frame(c) + attn_flops_per_frame(c)) * fps / 1e12, 1),

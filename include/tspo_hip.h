@@ -151,6 +151,23 @@ int tspo_selector_backward(const tspo_selector_weights* w, const float* img, con
                            const tspo_selector_grads* grads,
                            void* workspace, size_t workspace_bytes, tspo_stream_t stream);
 
+/* Same two calls with an option word.  TSPO_SEL_BF16X3: the projections / MLP /
+ * weight-gradient GEMMs run in split precision on the bf16 MFMA (every fp32
+ * operand x = hi + lo, products hi*hi + hi*lo + lo*hi, fp32 accumulate:
+ * ~1e-5 relative error instead of fp32's ~1e-6) - an opt-in for the TRAINING
+ * step, where the reference itself runs in bf16 (`--bf16`,
+ * train_deepspeed.sh:33, scripts/zero3.json:10); flags = 0 is identical to the calls
+ * above (exact fp32, the mode the greedy-index parity tests use).            */
+#define TSPO_SEL_BF16X3 1
+int tspo_selector_forward_ex(const tspo_selector_weights* w, const float* img, const float* txt, const float* clip,
+                             int B, int T, int D, int H, int M, int window, float tau,
+                             float* scores, float* temporal_attn,
+                             void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags);
+int tspo_selector_backward_ex(const tspo_selector_weights* w, const float* img, const float* txt,
+                              const float* dscores, int B, int T, int D, int H, int M, int window, float tau,
+                              const tspo_selector_grads* grads,
+                              void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags);
+
 /* ------------------------------------------------------------------------
  * Optimiser on the flat parameter bucket
  * ------------------------------------------------------------------------ */

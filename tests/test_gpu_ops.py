@@ -313,6 +313,40 @@ def test_selector_fwd_bwd_vs_oracle_autograd(case):
             np.testing.assert_allclose(got, ref, rtol=5e-4, atol=5e-5 * max(np.abs(ref).max(), 1e-12))
 
 
+def test_selector_bf16x3_split_precision_vs_exact():
+    """Opt-in split-precision GEMMs (TSPO_SEL_BF16X3): x = hi + lo in bf16, products hi*hi + hi*lo + lo*hi, fp32
+    accumulate.  Must agree with the exact fp32 path to ~1e-5 of each tensor's scale (and therefore with the oracle to
+    the tolerances of the exact-path tests, slightly widened), for the production width and for a ragged small shape."""
+    for (B, T, D, H, w) in ((2, 300, 768, 8, 12), (1, 37, 256, 8, 5)):
+        tau, M = 0.05, 2
+        img, txt = G_(synth.normal((B, T, D), 3100 + T)), G_(synth.normal((B, M, D), 3101))
+        clip, ds = G_(synth.normal((B, T), 3102, 0.1)), G_(synth.normal((B, T), 3103, 0.01))
+        flat = flat_from_state(synth.selector_state(D, seed=12, std=0.5 / np.sqrt(D), bias_std=0.05), D)
+        res = {}
+        for prec in ("fp32", "bf16x3"):
+            s, h, ws = ops.selector_forward(flat, img, txt, clip, H, w, tau, precision=prec)
+            g = torch.zeros_like(flat)
+            ops.selector_backward(flat, g, img, txt, ds, H, w, tau, ws, precision=prec)
+            res[prec] = (s.clone(), h.clone(), g.clone())
+        (s0, h0, g0), (s1, h1, g1) = res["fp32"], res["bf16x3"]
+        assert not torch.equal(g0, g1)                                   # the option really switches kernels
+        es = ((s1 - s0).abs().max() / s0.abs().max()).item()
+        eh = ((h1 - h0).abs().max() / h0.abs().max()).item()
+        offs = ops.flat_offsets(D)
+        eg = 0.0
+        for pn in O.SELECTOR_KEYS:
+            if "ffn_o" in pn or pn == "temporal.Self_k.bias":
+                continue
+            off, shape = offs[pn]
+            n = int(np.prod(shape))
+            a, b = g0[off:off + n], g1[off:off + n]
+            eg = max(eg, ((a - b).abs().max() / a.abs().max()).item())
+        print(f"\n[bf16x3 vs fp32, T={T} D={D}] scores {es:.2e}  h {eh:.2e}  grads {eg:.2e} (relative to each tensor's max)")
+        assert es < 2e-4 and eh < 5e-5 and eg < 2e-4
+    with pytest.raises(ValueError):
+        ops.selector_forward(flat, img, txt, clip, H, w, tau, precision="fp16")
+
+
 def test_selector_fwd_bwd_bitwise_repeatable():
     """Race screen for the LDS-DMA ring GEMMs / MFMA banded attention: the same inputs must give bit-identical scores and
     gradients every time (fixed-order split reductions, counted vmcnt waits) at the policy-step shape of the bench."""

@@ -14,7 +14,8 @@ txt = torch.randn(B, 1, 768, generator=gen, device=dev)
 clip = ops.clip_scores(txt, feats)
 rew = (torch.rand(B, G, generator=gen, device=dev) > 0.5).float() + torch.rand(B, G, generator=gen, device=dev)
 flat = bench.flat_from_state(bench.random_selector_state(768, dev), 768, dev)
-tr = PolicyTrainer(flat)
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+tr = PolicyTrainer(flat, gemm_precision=prec)
 for _ in range(5):
     tr.step(feats, txt, clip, lambda i: rew, G, k, tau)
 torch.cuda.synchronize()
@@ -24,4 +25,4 @@ for _ in range(n):
     tr.step(feats, txt, clip, lambda i: rew, G, k, tau)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print(f"policy step: {dt * 1e3:.3f} ms -> {B * G / dt:.0f} rollouts/s")
+print(f"policy step ({prec}): {dt * 1e3:.3f} ms -> {B * G / dt:.0f} rollouts/s")

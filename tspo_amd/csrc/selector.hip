@@ -10,6 +10,24 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// Split-precision operands ("bf16x3"): x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi); a product is
+// taken as hi*hi + hi*lo + lo*hi on the bf16 MFMA (fp32 accumulate), dropping only lo*lo ~ 2^-16 relative.  Optional
+// mode of the selector GEMMs for training (TSPO_SEL_BF16X3): ~1e-5 relative error instead of fp32's ~1e-6, far inside
+// the bf16 autocast the reference trains with, at several times the fp32-MFMA rate.
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+  union { bf16x8 v; uint32_t u[4]; } h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h.u[j] = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+    const float r0 = x[2 * j] - __uint_as_float(h.u[j] << 16);
+    const float r1 = x[2 * j + 1] - __uint_as_float(h.u[j] & 0xffff0000u);
+    l.u[j] = pack_bf16x2(r0, r1);
+  }
+  hi = h.v;
+  lo = l.v;
+}
 
 namespace {
 
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 // One workgroup = 64 x (32*WN) outputs, NWM x 2 waves of (64/NWM) x (16*WN); 3-deep ring with counted vmcnt waits.
 // WN = 3 (64x96 tiles) is used when N % 96 == 0: for D = 768 that makes BT=2048 x 768 exactly 256 workgroups (one
 // per CU) and x 2304 exactly 3 per CU, instead of 1.5 / 4.5 with 64x64 tiles, and gives 48 MFMAs per barrier.
-template <int EPI, int WN, int NWM, int NT_NST>
+template <int EPI, int WN, int NWM, int NT_NST, int SPLIT>
 __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ R, float* __restrict__ C,
@@ -162,16 +180,22 @@ __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float*
       }
     }
   };
-  auto wait_one_ahead = [&]() {   // all but the newest slab's DMA instructions of this wave have landed
-    if (hi) {
-      if (PW_HI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else if (PW_HI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (PW_HI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      if (PW_LO == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (PW_LO == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  // wait until slab kt has landed: the (NT_NST - 2) newer slabs of this wave (PW pieces each) may stay in flight
+  auto wait_ahead = [&](int ahead) {
+    const int cnt = ahead * (hi ? PW_HI : PW_LO);
+    switch (cnt) {   // s_waitcnt needs an immediate
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (conservative)
     }
   };
   static_assert(PW_HI >= 2 && PW_HI <= 5 && PW_LO >= 2, "unexpected DMA piece split");
@@ -186,17 +210,42 @@ __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float*
 #pragma unroll
   for (int j = 0; j < WN; ++j) offW[j] = 8192 + (wn * 16 * WN + j * 16 + l15) * 128;
   const int sw = l15 & 7;
-  stage(0, 0);
-  if (NT_NST == 3 && nk > 1) stage(1, 1);
+#pragma unroll
+  for (int t = 0; t < NT_NST - 1; ++t)
+    if (t < nk) stage(t, t);
   int ring = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // 3-deep: slab kt+1 stays in flight across the wait; 2-deep (more workgroups per CU instead): everything has landed
-    if (NT_NST == 3 && kt + 1 < nk) wait_one_ahead();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // slabs kt+1 .. kt+NT_NST-2 stay in flight across the wait (2-deep ring: everything has landed)
+    wait_ahead(min(NT_NST - 2, nk - 1 - kt));
     __builtin_amdgcn_s_barrier();   // slab kt visible to all waves; compute(kt-1) done everywhere -> its slot is free
     if (kt + NT_NST - 1 < nk) stage(kt + NT_NST - 1, ring >= 1 ? ring - 1 : NT_NST - 1);
     const char* cur = lds + ring * SLAB;
     ring = ring + 1 == NT_NST ? 0 : ring + 1;
+    if (SPLIT) {
+      // one bf16 MFMA spans the whole 32-deep slab: lane (row l15, q) owns k = 8q..8q+7 = 16-byte chunks 2q, 2q+1
+      const int c0 = (((2 * q) ^ sw) << 4), c1 = (((2 * q + 1) ^ sw) << 4);
+      bf16x8 ah[MI], al[MI], bh[WN], bl[WN];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(cur + offA[i] + c0), v = *reinterpret_cast<const f32x4*>(cur + offA[i] + c1);
+        const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        split_bf16x8(x, ah[i], al[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(cur + offW[j] + c0), v = *reinterpret_cast<const f32x4*>(cur + offW[j] + c1);
+        const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        split_bf16x8(x, bh[j], bl[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int co = (((kk * 4 + q) ^ sw) << 4);
@@ -211,6 +260,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float*
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][st], b[j][st], acc[i][j], 0, 0, 0);
+    }
     }
   }
 #pragma unroll
@@ -234,22 +284,27 @@ __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float*
     }
 }
 
-template <int EPI>
-int launch_gemm_nt(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
-                   hipStream_t st) {
+template <int EPI, int SPLIT>
+int launch_gemm_nt_p(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
+                     hipStream_t st) {
   const int mt = (M + 63) / 64;
   // ring depth 3 keeps two workgroups (16 waves) per CU; when the grid holds more than two workgroups per CU a 2-deep
   // ring (40 KB) lets three run at once instead of leaving the third for a half-empty second round
   if (K % 32 == 0 && N % 96 == 0) {
     if ((long)(N / 96) * mt > 512)
-      hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4, 2>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
-    else
-      hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4, 3>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
+      hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4, 2, SPLIT>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
+    else   // (a 6-deep ring for the split-precision case measured slower: 24-26 us vs 21-23 us for the DxD GEMMs)
+      hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4, 3, SPLIT>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
   } else if (K % 32 == 0)
-    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 2, 4, 3>), dim3(N / 64, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
+    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 2, 4, 3, SPLIT>), dim3(N / 64, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
   else
-    hipLaunchKernelGGL((gemm_f32_nt_kernel<EPI>), dim3(N / 64, mt), dim3(256), 0, st, A, W, bias, R, C, M, N, K);
+    hipLaunchKernelGGL((gemm_f32_nt_kernel<EPI>), dim3(N / 64, mt), dim3(256), 0, st, A, W, bias, R, C, M, N, K);   // (always exact)
   return tspo::check_launch("selector gemm_nt");
+}
+template <int EPI>
+int launch_gemm_nt(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
+                   hipStream_t st, bool split = false) {
+  return split ? launch_gemm_nt_p<EPI, 1>(A, W, bias, R, C, M, N, K, st) : launch_gemm_nt_p<EPI, 0>(A, W, bias, R, C, M, N, K, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -947,6 +1002,96 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tn_lds_kernel(const float* __
     }
 }
 
+// Split-precision (bf16x3) version of the weight-gradient GEMM: same 128x128 tile / 4 waves of 64x64 / interleaved
+// feature map, but a slab is 32 contraction rows = one bf16 MFMA k-step: lane (l15, q) owns rows 8q..8q+7, reads them as
+// 8 float4 per operand (4 interleaved feature tiles each), splits every value into hi + lo bf16 and issues
+// lo*hi + hi*lo + hi*hi for each of the 16 tile pairs (48 MFMAs per slab instead of 128 fp32 ones at half the rate).
+#define TS_ROWS 32
+#define TS_NST 3   // (4-deep measured no better)
+__global__ __launch_bounds__(256) void gemm_f32_tn_split_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                                float* __restrict__ Cp, int Mrows, int NI, int NJ,
+                                                                int chunk) {
+  __shared__ __attribute__((aligned(16))) char lds[TS_NST * 32768];   // per stage: A 32x512 B | B 32x512 B
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wi = wid >> 1, wj = wid & 1;
+  const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+  const int s = blockIdx.z;
+  const int mb = s * chunk, me = min(Mrows, mb + chunk);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nst = me > mb ? (me - mb + TS_ROWS - 1) / TS_ROWS : 0;
+  const int rlast = me > mb ? me - 1 : mb;
+  const int prow = lane >> 5, pcol = (lane & 31) << 2;
+  auto stage = [&](int t, int ring) {   // wave wid moves rows 8*wid..8*wid+7 of both slabs (2 rows per DMA instruction)
+    char* buf = lds + ring * 32768;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rr = wid * 8 + p * 2 + prow;
+      int r = mb + t * TS_ROWS + rr;
+      r = r < rlast ? r : rlast;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + (size_t)r * NI + i0 + pcol),
+                                       (__attribute__((address_space(3))) void*)(buf + (wid * 8 + p * 2) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)r * NJ + j0 + pcol),
+                                       (__attribute__((address_space(3))) void*)(buf + 16384 + (wid * 8 + p * 2) * 512), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < TS_NST - 1; ++t)
+    if (t < nst) stage(t, t);
+  const int offA = (wi * 64 + 4 * l15) * 4, offB = 16384 + (wj * 64 + 4 * l15) * 4;
+  int ring = 0;
+  for (int t = 0; t < nst; ++t) {
+    // slabs t+1, t+2 (8 DMA instructions each per wave) may stay in flight
+    const int ahead = min(TS_NST - 2, nst - 1 - t);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // slab t visible to all waves; everyone is done with slab t-1 -> its slot is free
+    if (t + TS_NST - 1 < nst) stage(t + TS_NST - 1, ring >= 1 ? ring - 1 : TS_NST - 1);
+    const char* cur = lds + ring * 32768;
+    ring = ring + 1 == TS_NST ? 0 : ring + 1;
+    f32x4 a4[8], b4[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = 8 * q + r;
+      const float keep = (mb + t * TS_ROWS + m < me) ? 1.f : 0.f;
+      a4[r] = *reinterpret_cast<const f32x4*>(cur + offA + m * 512) * keep;
+      b4[r] = *reinterpret_cast<const f32x4*>(cur + offB + m * 512);
+    }
+    bf16x8 bh[4], bl[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const float x[8] = {b4[0][cb], b4[1][cb], b4[2][cb], b4[3][cb], b4[4][cb], b4[5][cb], b4[6][cb], b4[7][cb]};
+      split_bf16x8(x, bh[cb], bl[cb]);
+    }
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca) {
+      const float x[8] = {a4[0][ca], a4[1][ca], a4[2][ca], a4[3][ca], a4[4][ca], a4[5][ca], a4[6][ca], a4[7][ca]};
+      bf16x8 ah, al;
+      split_bf16x8(x, ah, al);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[cb], acc[ca][cb], 0, 0, 0);
+        acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[cb], acc[ca][cb], 0, 0, 0);
+        acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[cb], acc[ca][cb], 0, 0, 0);
+      }
+    }
+  }
+  float* cp = Cp + (size_t)s * NI * NJ;
+#pragma unroll
+  for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + wi * 64 + 4 * (q * 4 + r) + ca;
+      f32x4 v = {acc[ca][0][r], acc[ca][1][r], acc[ca][2][r], acc[ca][3][r]};
+      *reinterpret_cast<f32x4*>(cp + (size_t)i * NJ + j0 + wj * 64 + 4 * l15) = v;
+    }
+}
+
 // One launch for all split reductions of a backward pass: segment g holds S planes of n floats (plane stride n) and
 // sums them in plane order into out (fixed order -> deterministic).
 #define RED_SEGS 6
@@ -1100,10 +1245,12 @@ extern "C" size_t tspo_selector_workspace_bytes(int B, int T, int D, int H, int 
   return carve(nullptr, B, T, D, H, M, window).bytes;
 }
 
-extern "C" int tspo_selector_forward(const tspo_selector_weights* w, const float* img, const float* txt,
-                                     const float* clip, int B, int T, int D, int H, int M, int window, float tau,
-                                     float* scores, float* temporal_attn, void* workspace, size_t workspace_bytes,
-                                     tspo_stream_t stream) {
+static int selector_forward_impl(const tspo_selector_weights* w, const float* img, const float* txt,
+                                 const float* clip, int B, int T, int D, int H, int M, int window, float tau,
+                                 float* scores, float* temporal_attn, void* workspace, size_t workspace_bytes,
+                                 tspo_stream_t stream, int flags) {
+  const bool split = (flags & TSPO_SEL_BF16X3) != 0;
+  TSPO_REQUIRE((flags & ~TSPO_SEL_BF16X3) == 0, "selector_forward: unknown flags 0x%x", flags);
   TSPO_REQUIRE(w && img && txt && scores && workspace, "selector_forward: null pointer");
   TSPO_REQUIRE(w->wqkv && w->bqkv && w->w1 && w->b1 && w->w2 && w->b2, "selector_forward: null weight pointer");
   if (int e = check_dims("selector_forward", B, T, D, H, M, window)) return e;
@@ -1117,13 +1264,13 @@ extern "C" int tspo_selector_forward(const tspo_selector_weights* w, const float
   int nb = (int)((tot + 255) / 256);
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(posenc_add_kernel, dim3(nb), dim3(256), 0, st, img, s.xpe, T, D, tot);
-  if (int e = launch_gemm_nt<EPI_NONE>(s.xpe, w->wqkv, w->bqkv, nullptr, s.qkv, BT, 3 * D, D, st)) return e;
+  if (int e = launch_gemm_nt<EPI_NONE>(s.xpe, w->wqkv, w->bqkv, nullptr, s.qkv, BT, 3 * D, D, st, split)) return e;
   const long pairs = (long)BT * H;
   if (!band_mfma(0, s.qkv, s.ctx, s.P, nullptr, nullptr, nullptr, B, T, D, H, window, st))
     hipLaunchKernelGGL(band_attn_fwd_kernel, dim3((unsigned)((pairs + 7) / 8)), dim3(256), 0, st, s.qkv, s.ctx, s.P, B, T,
                        D, H, window);
-  if (int e = launch_gemm_nt<EPI_RELU>(s.ctx, w->w1, w->b1, nullptr, s.h1, BT, D, D, st)) return e;
-  if (int e = launch_gemm_nt<EPI_RESID>(s.h1, w->w2, w->b2, img, s.h2, BT, D, D, st)) return e;
+  if (int e = launch_gemm_nt<EPI_RELU>(s.ctx, w->w1, w->b1, nullptr, s.h1, BT, D, D, st, split)) return e;
+  if (int e = launch_gemm_nt<EPI_RESID>(s.h1, w->w2, w->b2, img, s.h2, BT, D, D, st, split)) return e;
   hipLaunchKernelGGL(score_fwd_kernel, dim3((BT + 3) / 4), dim3(256), 0, st, s.h2, txt, clip, scores, B, T, D, M, tau);
   if (temporal_attn) {
     hipError_t e = hipMemcpyAsync(temporal_attn, s.h2, tot * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1132,11 +1279,29 @@ extern "C" int tspo_selector_forward(const tspo_selector_weights* w, const float
   return tspo::check_launch("selector_forward");
 }
 
+extern "C" int tspo_selector_forward(const tspo_selector_weights* w, const float* img, const float* txt,
+                                     const float* clip, int B, int T, int D, int H, int M, int window, float tau,
+                                     float* scores, float* temporal_attn, void* workspace, size_t workspace_bytes,
+                                     tspo_stream_t stream) {
+  return selector_forward_impl(w, img, txt, clip, B, T, D, H, M, window, tau, scores, temporal_attn, workspace,
+                               workspace_bytes, stream, 0);
+}
+extern "C" int tspo_selector_forward_ex(const tspo_selector_weights* w, const float* img, const float* txt,
+                                        const float* clip, int B, int T, int D, int H, int M, int window, float tau,
+                                        float* scores, float* temporal_attn, void* workspace, size_t workspace_bytes,
+                                        tspo_stream_t stream, int flags) {
+  return selector_forward_impl(w, img, txt, clip, B, T, D, H, M, window, tau, scores, temporal_attn, workspace,
+                               workspace_bytes, stream, flags);
+}
+
 namespace {
-int weight_grad(const float* dY, const float* X, float* part, int BT, int NI, int NJ, const SelWs& s, hipStream_t st) {
+int weight_grad(const float* dY, const float* X, float* part, int BT, int NI, int NJ, const SelWs& s, hipStream_t st,
+                bool split) {
   const int chunk = ((BT + s.S - 1) / s.S + 3) / 4 * 4;
   dim3 grid((NJ + 127) / 128, (NI + 127) / 128, s.S);
-  if (NI % 128 == 0 && NJ % 128 == 0)
+  if (split && NI % 128 == 0 && NJ % 128 == 0)
+    hipLaunchKernelGGL(gemm_f32_tn_split_kernel, grid, dim3(256), 0, st, dY, X, part, BT, NI, NJ, chunk);
+  else if (NI % 128 == 0 && NJ % 128 == 0)
     hipLaunchKernelGGL(gemm_f32_tn_lds_kernel, grid, dim3(256), 0, st, dY, X, part, BT, NI, NJ, chunk);
   else
     hipLaunchKernelGGL(gemm_f32_tn_kernel, grid, dim3(256), 0, st, dY, X, part, BT, NI, NJ, chunk);
@@ -1144,10 +1309,12 @@ int weight_grad(const float* dY, const float* X, float* part, int BT, int NI, in
 }
 }  // namespace
 
-extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const float* img, const float* txt,
-                                      const float* dscores, int B, int T, int D, int H, int M, int window, float tau,
-                                      const tspo_selector_grads* g, void* workspace, size_t workspace_bytes,
-                                      tspo_stream_t stream) {
+static int selector_backward_impl(const tspo_selector_weights* w, const float* img, const float* txt,
+                                  const float* dscores, int B, int T, int D, int H, int M, int window, float tau,
+                                  const tspo_selector_grads* g, void* workspace, size_t workspace_bytes,
+                                  tspo_stream_t stream, int flags) {
+  const bool split = (flags & TSPO_SEL_BF16X3) != 0;
+  TSPO_REQUIRE((flags & ~TSPO_SEL_BF16X3) == 0, "selector_backward: unknown flags 0x%x", flags);
   TSPO_REQUIRE(w && img && txt && dscores && g && workspace, "selector_backward: null pointer");
   TSPO_REQUIRE(g->wqkv && g->bqkv && g->w1 && g->b1 && g->w2 && g->b2, "selector_backward: null grad pointer");
   if (int e = check_dims("selector_backward", B, T, D, H, M, window)) return e;
@@ -1165,11 +1332,11 @@ extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const floa
   // score -> dh2
   hipLaunchKernelGGL(score_bwd_kernel, dim3((BT + 3) / 4), dim3(256), 0, st, s.h2, txt, dscores, s.dh2, B, T, D, M, tau);
   // mlp.2
-  if (int e = weight_grad(s.dh2, s.h1, part_w2, BT, D, D, s, st)) return e;
-  if (int e = launch_gemm_nt<EPI_MASK>(s.dh2, s.w2t, nullptr, s.h1, s.dh1, BT, D, D, st)) return e;
+  if (int e = weight_grad(s.dh2, s.h1, part_w2, BT, D, D, s, st, split)) return e;
+  if (int e = launch_gemm_nt<EPI_MASK>(s.dh2, s.w2t, nullptr, s.h1, s.dh1, BT, D, D, st, split)) return e;
   // mlp.0
-  if (int e = weight_grad(s.dh1, s.ctx, part_w1, BT, D, D, s, st)) return e;
-  if (int e = launch_gemm_nt<EPI_NONE>(s.dh1, s.w1t, nullptr, nullptr, s.dctx, BT, D, D, st)) return e;
+  if (int e = weight_grad(s.dh1, s.ctx, part_w1, BT, D, D, s, st, split)) return e;
+  if (int e = launch_gemm_nt<EPI_NONE>(s.dh1, s.w1t, nullptr, nullptr, s.dctx, BT, D, D, st, split)) return e;
   // banded attention
   const long pairs = (long)BT * H;
   const unsigned pb = (unsigned)((pairs + 7) / 8);
@@ -1180,7 +1347,7 @@ extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const floa
     hipLaunchKernelGGL(band_attn_bwd_kv_kernel, dim3(pb), dim3(256), 0, st, s.qkv, s.P, s.dS, s.dctx, s.dqkv, B, T, D, H,
                        window);
   // q/k/v projections
-  if (int e = weight_grad(s.dqkv, s.xpe, part_qkv, BT, 3 * D, D, s, st)) return e;
+  if (int e = weight_grad(s.dqkv, s.xpe, part_qkv, BT, 3 * D, D, s, st, split)) return e;
   // bias grads: column sums of dh2 | dh1 | dqkv, then every split reduction (3 weights + 3 biases) in one launch
   const int rows_per = (BT + s.CS - 1) / s.CS;
   hipLaunchKernelGGL(colsum3_kernel, dim3(5 * D / 64, s.CS), dim3(256), 0, st, s.dh2, s.dh1, s.dqkv, s.cpart, BT, D,
@@ -1205,6 +1372,20 @@ extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const floa
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L);
   (void)img;
   return tspo::check_launch("selector_backward");
+}
+
+extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const float* img, const float* txt,
+                                      const float* dscores, int B, int T, int D, int H, int M, int window, float tau,
+                                      const tspo_selector_grads* g, void* workspace, size_t workspace_bytes,
+                                      tspo_stream_t stream) {
+  return selector_backward_impl(w, img, txt, dscores, B, T, D, H, M, window, tau, g, workspace, workspace_bytes, stream, 0);
+}
+extern "C" int tspo_selector_backward_ex(const tspo_selector_weights* w, const float* img, const float* txt,
+                                         const float* dscores, int B, int T, int D, int H, int M, int window, float tau,
+                                         const tspo_selector_grads* g, void* workspace, size_t workspace_bytes,
+                                         tspo_stream_t stream, int flags) {
+  return selector_backward_impl(w, img, txt, dscores, B, T, D, H, M, window, tau, g, workspace, workspace_bytes, stream,
+                                flags);
 }
 
 extern "C" int tspo_clip_scores(const float* txt, const float* feat, int B, int T, int D, int M, float* clip,

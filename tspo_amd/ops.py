@@ -161,10 +161,23 @@ def selector_workspace(B, T, D, H, M, window, device) -> torch.Tensor:
     return torch.empty((n,), dtype=torch.uint8, device=device)
 
 
+SEL_BF16X3 = 1   # include/tspo_hip.h: TSPO_SEL_BF16X3
+
+
+def _sel_flags(precision: str) -> int:
+    if precision == "fp32":
+        return 0
+    if precision == "bf16x3":
+        return SEL_BF16X3
+    raise ValueError(f"selector precision must be 'fp32' or 'bf16x3', got {precision!r}")
+
+
 def selector_forward(flat: torch.Tensor, img: torch.Tensor, txt: torch.Tensor, clip: Optional[torch.Tensor],
-                     H: int, window: int, tau: float, want_attn: bool = True, ws: Optional[torch.Tensor] = None):
+                     H: int, window: int, tau: float, want_attn: bool = True, ws: Optional[torch.Tensor] = None,
+                     precision: str = "fp32"):
     """flat: f32 parameter bucket (FLAT_LAYOUT). img [B,T,D], txt [B,M,D], clip [B,T] ->
-    (scores [B,T] f32, temporal_attn [B,T,D] f32 | None, workspace)."""
+    (scores [B,T] f32, temporal_attn [B,T,D] f32 | None, workspace).
+    precision="bf16x3" (opt-in, training): split-precision GEMMs on the bf16 MFMA, ~1e-5 relative error."""
     _need_gpu(flat, img, txt, clip)
     assert flat.dtype == torch.float32 and flat.is_contiguous()
     x, e = _f32c(img), _f32c(txt)
@@ -176,13 +189,14 @@ def selector_forward(flat: torch.Tensor, img: torch.Tensor, txt: torch.Tensor, c
     scores = torch.empty((B, T), dtype=torch.float32, device=x.device)
     attn = torch.empty((B, T, D), dtype=torch.float32, device=x.device) if want_attn else None
     w = _sel_structs(flat, D, _lib.SelectorWeights)
-    check(_lib.lib().tspo_selector_forward(C.byref(w), _ptr(x), _ptr(e), _ptr(c), B, T, D, H, M, int(window), float(tau),
-                                           _ptr(scores), _ptr(attn), _ptr(ws), ws.numel(), _stream()),
-          "tspo_selector_forward")
+    check(_lib.lib().tspo_selector_forward_ex(C.byref(w), _ptr(x), _ptr(e), _ptr(c), B, T, D, H, M, int(window), float(tau),
+                                              _ptr(scores), _ptr(attn), _ptr(ws), ws.numel(), _stream(),
+                                              _sel_flags(precision)), "tspo_selector_forward")
     return scores, attn, ws
 
 
-def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dscores, H, window, tau, ws):
+def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dscores, H, window, tau, ws,
+                      precision: str = "fp32"):
     """Writes the gradient of every trainable tensor into `flat_grad` (same layout as `flat`)."""
     _need_gpu(flat, flat_grad, img, txt, dscores, ws)
     x, e, d = _f32c(img), _f32c(txt), _f32c(dscores)
@@ -190,8 +204,9 @@ def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dsc
     M = e.shape[1]
     w = _sel_structs(flat, D, _lib.SelectorWeights)
     g = _sel_structs(flat_grad, D, _lib.SelectorGrads)
-    check(_lib.lib().tspo_selector_backward(C.byref(w), _ptr(x), _ptr(e), _ptr(d), B, T, D, H, M, int(window), float(tau),
-                                            C.byref(g), _ptr(ws), ws.numel(), _stream()), "tspo_selector_backward")
+    check(_lib.lib().tspo_selector_backward_ex(C.byref(w), _ptr(x), _ptr(e), _ptr(d), B, T, D, H, M, int(window), float(tau),
+                                               C.byref(g), _ptr(ws), ws.numel(), _stream(), _sel_flags(precision)),
+          "tspo_selector_backward")
 
 
 def grad_norm_scale(grad: torch.Tensor, n: int, pre_scale: float = 1.0, max_norm: float = 1.0) -> torch.Tensor:

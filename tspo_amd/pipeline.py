@@ -64,7 +64,11 @@ class PolicyTrainer:
 
     def __init__(self, flat: torch.Tensor, dim: int = 768, heads: int = 8, window_size: int = 12,
                  lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 max_grad_norm: float = 1.0, seed: int = 2024, process_group=None):
+                 max_grad_norm: float = 1.0, seed: int = 2024, process_group=None, gemm_precision: str = "fp32"):
+        # gemm_precision: "fp32" (exact fp32 MFMA, default) or "bf16x3" (opt-in split-precision GEMMs, ~1e-5 relative
+        # error; the reference trains in bf16, train_deepspeed.sh:33)
+        ops._sel_flags(gemm_precision)
+        self.gemm_precision = gemm_precision
         self.flat = flat
         self.grad = torch.zeros_like(flat)
         self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
@@ -86,7 +90,7 @@ class PolicyTrainer:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=feats.device)
         scores, _, _ = ops.selector_forward(self.flat, feats, txt, clip, self.heads, self.window, tau, want_attn=False,
-                                            ws=self._ws)
+                                            ws=self._ws, precision=self.gemm_precision)
         out = ops.gumbel_topk(scores, k, G, noise=noise, seed=self.seed, offset=self.step_no)
         return scores, out["idx"], out["logp"]
 
@@ -95,7 +99,8 @@ class PolicyTrainer:
         B = feats.shape[0]
         adv = ops.grpo_advantage(rewards)
         dlog, loss = ops.pg_grad_logits(logp, idx, adv, scale=1.0 / B)
-        ops.selector_backward(self.flat, self.grad, feats, txt, dlog, self.heads, self.window, tau, self._ws)
+        ops.selector_backward(self.flat, self.grad, feats, txt, dlog, self.heads, self.window, tau, self._ws,
+                              precision=self.gemm_precision)
         world = self.world()
         if world > 1:
             import torch.distributed as dist
