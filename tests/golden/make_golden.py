@@ -226,12 +226,99 @@ def gen_clip(out):
         run(cfgd, n, tag, tag == "clip_tiny")
 
 
+def _ref_functions(relpath, names, namespace):
+    """Evaluate the named top-level functions of a reference file that cannot be imported here (its module imports
+    trl / deepspeed / decord / math_verify at the top): the function definitions are taken from the file's AST at
+    generation time and executed in `namespace`.  Nothing of the source text is stored."""
+    import ast
+    src = open(os.path.join("/root/reference", relpath)).read()
+    tree = ast.parse(src)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in picked) == sorted(names), (relpath, [n.name for n in picked])
+    mod = ast.Module(body=picked, type_ignores=[])
+    exec(compile(mod, relpath, "exec"), namespace)
+    return namespace
+
+
+GLUE_STRINGS = [
+    "B", "(B).", "b) because a cat appears", "The answer is C.", "Answer: (d)", "  E  ", "A.", "(a)", "a", "option b",
+    "because", "", "   ", "f", "zebra", "Z) none", "I think it is (C) or (D)", "<answer>B</answer>", "<answer> c </answer>",
+    "<think>it is a dog</think><answer>A</answer>", "<think>x</think>\n  <answer>D</answer> trailing",
+    "<answer>A</answer><think>late</think>", "no tags at all", "12345", "a-b", "A,B", "xAy", "_b_", "b2", "3c", "E!",
+    "the end", "d\ne", "Bee", "(B", "B)", "[c]", "{d}", "e.g. this", "i.e. that", "ABCD",
+]
+
+
+def gen_glue(_out):
+    """Reward glue (src/open_tspo/tspo.py:86-166, tspo_trainer.py:570-573) and the needle-in-haystack sample builder
+    (src/open_tspo/trainer/utils.py:15-25,177-200) evaluated from the reference's own function bodies.  math_verify is
+    not installed here: parse() raises, so accuracy_reward takes its string-matching branch (the documented fallback of
+    the reference itself, tspo.py:118-136).  Written as JSON (strings + nested lists) to tests/golden/glue.json."""
+    import datetime as _dt
+    import json
+    import re
+
+    def _no_math_verify(*a, **k):
+        raise RuntimeError("math_verify is not available")
+
+    ns = {"re": re, "os": os, "torch": torch, "np": np, "datetime": _dt.datetime, "parse": _no_math_verify,
+          "verify": _no_math_verify}
+    _ref_functions("src/open_tspo/tspo.py", ["map_prediction_to_option", "accuracy_reward", "temporal_localization_reward",
+                                            "format_reward"], ns)
+    g = {"strings": GLUE_STRINGS}
+    g["map_prediction_to_option"] = [ns["map_prediction_to_option"](x) for x in GLUE_STRINGS]
+    g["format_reward"] = ns["format_reward"]([[{"content": x}] for x in GLUE_STRINGS])
+    sols = ["<answer>B</answer>", "B", "<answer>(c)</answer>", "<think>t</think><answer> D. the dog </answer>", "e", "<answer></answer>", ""]
+    g["solutions"] = sols
+    g["accuracy_reward"] = []
+    for sol in sols:
+        comps = [[{"content": x}] for x in GLUE_STRINGS]
+        sel = [(None, torch.zeros(1, dtype=torch.long))] * len(comps)
+        g["accuracy_reward"].append(ns["accuracy_reward"](comps, [sol] * len(comps), sel, None))
+    # temporal localisation reward: sum(mask[idx]) / k for each rollout (sel_idx is the (idx.clone(), idx) pair)
+    tl = []
+    for T, k, G, seed in [(64, 8, 4, 1), (650, 16, 8, 2), (50, 8, 8, 3), (7, 7, 2, 4)]:
+        mask = synth.uniform((T,), 600 + seed) > 0.6
+        idx = [np.sort(np.argsort(synth.uniform((T,), 700 + seed * 31 + gidx))[:k]) for gidx in range(G)]
+        sel = [(torch.from_numpy(i), torch.from_numpy(i)) for i in idx]
+        r = ns["temporal_localization_reward"](None, None, sel, torch.from_numpy(mask))
+        tl.append({"T": T, "k": k, "G": G, "seed": seed, "rewards": r})
+    g["temporal_localization_reward"] = tl
+    # combination of the reward columns (tspo_trainer.py:570-573), both item types
+    rpf = torch.tensor([[1.0, 0.25], [0.0, 0.5], [1.0, 1.0], [0.0, 0.0]])
+    g["combine"] = {"rewards_per_func": rpf.tolist(), "specific": rpf.sum(dim=1).tolist(),
+                    "general": (rpf[:, 0:1].sum(dim=1) + 1).tolist()}
+
+    # ---- needle-in-haystack builder: frames carry their own identity, so the merged "video" IS the index map ----
+    ns2 = {"np": np, "torch": torch}
+    _ref_functions("src/open_tspo/trainer/utils.py", ["repeat_videos", "shuffle_clips"], ns2)
+    hay = []
+    for L, rep, n_wrong, sample_len, seed in [(128, 4, 12, 50, 11), (128, 1, 12, 50, 12), (77, 3, 12, 50, 13),
+                                              (40, 2, 12, 50, 14), (50, 4, 3, 50, 15), (300, 2, 5, 20, 16)]:
+        np.random.seed(seed)
+        video = np.arange(L, dtype=np.int64).reshape(L, 1, 1, 1) * np.ones((1, 1, 1, 3), np.int64)      # frame i == i
+        true_videos = ns2["repeat_videos"](video, repeat_times=rep, sample_len=sample_len)
+        glen = len(true_videos[0])
+        wrong = [(-1 - w) * np.ones((glen, 1, 1, 3), np.int64) for w in range(n_wrong)]               # distractor w == -1-w
+        merged, mask = ns2["shuffle_clips"](true_videos, wrong)
+        hay.append({"L": L, "repeat_times": rep, "n_wrong": n_wrong, "sample_len": sample_len, "seed": seed,
+                    "frame_ids": merged[:, 0, 0, 0].tolist(), "mask": mask.numpy().astype(int).tolist()})
+    g["haystack"] = hay
+    path = os.path.join(HERE, "glue.json")
+    with open(path, "w") as f:
+        json.dump(g, f, indent=0)
+    print(f"glue: -> {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 def main():
-    groups = {"selector": gen_selector, "misc": gen_misc, "gumbel": gen_gumbel, "train": gen_train, "clip": gen_clip}
+    groups = {"selector": gen_selector, "misc": gen_misc, "gumbel": gen_gumbel, "train": gen_train, "clip": gen_clip,
+              "glue": gen_glue}
     which = sys.argv[1:] or list(groups)
     for g in which:
         out = {}
         groups[g](out)
+        if g == "glue":
+            continue          # writes glue.json itself (strings, nested lists)
         path = os.path.join(HERE, f"{g}.npz")
         np.savez_compressed(path, **out)
         print(f"{g}: {len(out)} arrays -> {path} ({os.path.getsize(path) / 1024:.1f} KiB)")

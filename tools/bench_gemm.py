@@ -1,14 +1,19 @@
 #!/usr/bin/env python
 """Micro-benchmark + check of the bf16 MFMA GEMM on the CLIP-L shapes (M = 257*T rows).
 Variants are timed interleaved (rotating order) over several rounds; the median per variant is reported
-(single back-to-back runs showed an ~8 % position bias)."""
+(single back-to-back runs showed an ~8 % position bias).  Variant -1 is the same-box yardstick: the vendor GEMM
+(torch.nn.functional.linear -> hipBLASLt) on the same operands, WITHOUT the activation / residual epilogue the
+hand-written kernels fuse (tool only; the product never calls it).
+
+    python tools/bench_gemm.py T variants rounds        e.g.  1024 6,80,-1 6
+Every variant's full output is also compared with the first variant's (bitwise where the K order is the same)."""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tspo_amd import ops
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [6, 80, -1]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 M = 257 * T
 dev = "cuda"
@@ -18,6 +23,7 @@ for name, N, K, act, resid in shapes:
     A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g, device=dev) * 0.03).to(torch.bfloat16)
     bias = torch.randn(N, generator=g, device=dev) * 0.1
+    bias16 = bias.to(torch.bfloat16)
     R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16) if resid else None
     rows = torch.randint(0, M, (512,), device=dev)
     rr = A[rows].float() @ W.float().t() + bias
@@ -25,12 +31,28 @@ for name, N, K, act, resid in shapes:
         rr = rr * torch.sigmoid(1.702 * rr)
     if resid:
         rr = rr + R[rows].float()
-    fns = {v: (lambda v=v: ops.gemm_bf16(A, W, bias=bias, residual=R, act=act | (v << 8))) for v in variants}
-    errs = {}
+
+    def mk(v):
+        if v == -1:
+            return lambda: torch.nn.functional.linear(A, W, bias16)
+        return lambda: ops.gemm_bf16(A, W, bias=bias, residual=R, act=act | (v << 8))
+
+    fns = {v: mk(v) for v in variants}
+    errs, same = {}, {}
+    first = None
     for v, f in fns.items():
         out = f()
         torch.cuda.synchronize()
-        errs[v] = (out[rows].float() - rr).abs().max().item() / rr.abs().max().item()
+        if v != -1:
+            errs[v] = (out[rows].float() - rr).abs().max().item() / rr.abs().max().item()
+            if first is None:
+                first = out
+            same[v] = bool(torch.equal(out, first))
+            if not same[v]:
+                same[v] = "maxdiff %.3g" % (out.float() - first.float()).abs().max().item()
+        else:
+            errs[v], same[v] = float("nan"), "-"
+        del out
         for _ in range(2):
             f()
     times = {v: [] for v in variants}
@@ -46,5 +68,7 @@ for name, N, K, act, resid in shapes:
             times[v].append(st.elapsed_time(en) / 5)
     for v in variants:
         ms = statistics.median(times[v])
-        print(f"{name:4s} N={N:5d} K={K:5d} variant {v:3d}: median {ms:7.3f} ms (min {min(times[v]):7.3f})  "
-              f"{2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s  relerr {errs[v]:.2e}", flush=True)
+        tag = "hipBLASLt (no act/resid)" if v == -1 else f"variant {v:3d}"
+        print(f"{name:4s} N={N:5d} K={K:5d} {tag:>24s}: median {ms:7.3f} ms (min {min(times[v]):7.3f})  "
+              f"{2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s  relerr {errs[v]:.2e}  same-as-first {same[v]}", flush=True)
+    del first

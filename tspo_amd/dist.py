@@ -32,11 +32,36 @@ def shard_prompts(n_global: int, world: int, rank: int) -> range:
     return range(start, start + base + (1 if rank < rem else 0))
 
 
+def _host_staged(group) -> bool:
+    """gloo moves CUDA tensors through the host itself only in some builds; stage explicitly (tests: two ranks on ONE
+    GPU cannot use RCCL, which needs one device per rank)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def allreduce_bucket_(bucket: torch.Tensor, n: int, group=None, average: bool = False) -> int:
+    """THE gradient exchange of the data-parallel step: one in-place all-reduce(SUM) of bucket[:n] over the ranks of
+    `group` ("nccl" = RCCL over xGMI on MI355X).  Returns the world size; with average=True the result is divided by it
+    (PolicyTrainer keeps the sum and folds 1/world into the clip coefficient instead of a second pass over the bucket).
+    No-op (returns 1) when torch.distributed is not initialised."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world > 1:
+        view = bucket[:n]
+        if view.is_cuda and _host_staged(group):
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            view.copy_(host)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            view.div_(world)
+    return world
+
+
 def allreduce_mean_(bucket: torch.Tensor, n: int, group=None) -> torch.Tensor:
-    """In-place mean over ranks of bucket[:n] (one collective)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(bucket[:n], op=dist.ReduceOp.SUM, group=group)
-        bucket[:n].div_(dist.get_world_size(group))
+    """In-place mean over ranks of bucket[:n] (allreduce_bucket_ with average=True)."""
+    allreduce_bucket_(bucket, n, group, average=True)
     return bucket
 
 
@@ -87,6 +112,11 @@ def sharded_apply(fn, x: torch.Tensor, group=None) -> torch.Tensor:
     if local is not None:
         buf[: local.shape[0]] = local
     out = torch.empty((world * per,) + tuple(probe.shape[1:]), dtype=probe.dtype, device=probe.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
+    if buf.is_cuda and _host_staged(group):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, buf.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, buf, group=group)
     parts = [out[r * per: r * per + len(shard_rows(n, world, r))] for r in range(world)]
     return torch.cat(parts, dim=0)

@@ -209,11 +209,15 @@ def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dsc
           "tspo_selector_backward")
 
 
-def grad_norm_scale(grad: torch.Tensor, n: int, pre_scale: float = 1.0, max_norm: float = 1.0) -> torch.Tensor:
-    """-> device tensor [2] = (||g||, clip coefficient * pre_scale); no host sync."""
-    _need_gpu(grad)
-    out = torch.empty((2,), dtype=torch.float32, device=grad.device)
-    ws = torch.empty((2048,), dtype=torch.uint8, device=grad.device)
+def grad_norm_scale(grad: torch.Tensor, n: int, pre_scale: float = 1.0, max_norm: float = 1.0,
+                    out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> device tensor [2] = (||g||, clip coefficient * pre_scale); no host sync.  `out` / `ws` (>= 2048 bytes) let a
+    caller that runs this every step keep its own buffers instead of two allocations per call."""
+    _need_gpu(grad, out, ws)
+    if out is None:
+        out = torch.empty((2,), dtype=torch.float32, device=grad.device)
+    if ws is None:
+        ws = torch.empty((2048,), dtype=torch.uint8, device=grad.device)
     check(_lib.lib().tspo_grad_norm_scale(_ptr(grad), n, float(pre_scale), float(max_norm), _ptr(out), _ptr(ws),
                                           ws.numel(), _stream()), "tspo_grad_norm_scale")
     return out

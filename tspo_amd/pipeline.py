@@ -59,12 +59,34 @@ class FrameScorer:
         return idx, scores, feats
 
 
+class RolloutContext:
+    """What `PolicyTrainer.rollout` saved for the matching backward: the selector workspace holding the activations
+    of THAT forward, the shapes / temperature they belong to, and the parameter version they were computed with.
+    Opaque to callers; `PolicyTrainer.backward` validates and consumes it (a context is good for one backward)."""
+    __slots__ = ("ws", "shape", "M", "tau", "param_version", "serial", "consumed", "owner")
+
+    def __init__(self, ws, shape, M, tau, param_version, serial, owner):
+        self.ws, self.shape, self.M, self.tau = ws, tuple(shape), M, float(tau)
+        self.param_version, self.serial, self.consumed, self.owner = param_version, serial, False, owner
+
+
 class PolicyTrainer:
-    """Data-parallel TSPO policy step on one rank.  `flat`/`grad` are the fp32 buckets of ops.FLAT_LAYOUT."""
+    """Data-parallel TSPO policy step on one rank.  `flat`/`grad` are the fp32 buckets of ops.FLAT_LAYOUT.
+
+    One optimizer step = `grad_accum_steps` micro-steps (train_deepspeed.sh:31 uses 2), each
+        scores, idx, logp, ctx = rollout(feats, txt, clip, G, k, tau)      # selector forward once + G rollouts
+        rewards = <frozen video-LLM pass, stock PyTorch>                    # [B, G]
+        backward(ctx, feats, txt, logp, idx, rewards)                       # accumulates into the flat grad bucket
+    and, on the accumulation boundary only, `optimizer_step()`: ONE all-reduce of the bucket
+    (`reduce_fn`, default tspo_amd.dist.allreduce_bucket_ = RCCL over xGMI), clip-norm of the mean, fused AdamW.
+    `step()` / `update()` wrap these for the common one-micro-batch case.
+    """
 
     def __init__(self, flat: torch.Tensor, dim: int = 768, heads: int = 8, window_size: int = 12,
                  lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 max_grad_norm: float = 1.0, seed: int = 2024, process_group=None, gemm_precision: str = "fp32"):
+                 max_grad_norm: float = 1.0, seed: int = 2024, process_group=None, gemm_precision: str = "fp32",
+                 grad_accum_steps: int = 1, lr_schedule: Optional[Callable[[int], float]] = None,
+                 reduce_fn: Optional[Callable] = None, rank: Optional[int] = None):
         # gemm_precision: "fp32" (exact fp32 MFMA, default) or "bf16x3" (opt-in split-precision GEMMs, ~1e-5 relative
         # error; the reference trains in bf16, train_deepspeed.sh:33)
         ops._sel_flags(gemm_precision)
@@ -74,54 +96,162 @@ class PolicyTrainer:
         self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
         self.dim, self.heads, self.window = dim, heads, window_size
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.lr_schedule = lr_schedule          # optimizer step (0-based) -> learning rate; None = constant `lr`
         self.n_train = ops.trainable_numel(dim)
-        self.seed, self.step_no = seed, 0
+        self.seed, self.step_no = seed, 0       # step_no = optimizer steps taken (AdamW bias correction)
         self.pg = process_group
-        self._ws = None
+        if reduce_fn is None:
+            from .dist import allreduce_bucket_
+            reduce_fn = allreduce_bucket_
+        self.reduce_fn = reduce_fn              # (bucket, n, group) -> world size; leaves the SUM over ranks in bucket[:n]
+        self.grad_accum_steps = int(grad_accum_steps)
+        assert self.grad_accum_steps >= 1
+        self._micro = 0                         # micro-steps accumulated since the last optimizer step
+        self._rollouts = 0                      # rollout() calls so far: Philox offset (fresh noise for every call)
+        self._param_version = 0                 # bumped by optimizer_step(): a context from before it is stale
+        self._ws_pool = []                      # selector workspaces returned by consumed contexts
+        self._gmicro = None                     # scratch bucket of the 2nd.. micro-step's gradient
+        self._norm_out = torch.empty((2,), dtype=torch.float32, device=flat.device)
+        self._norm_ws = torch.empty((2048,), dtype=torch.uint8, device=flat.device)
+        self._rank = rank
 
+    # ---- topology -----------------------------------------------------------------------------------------
     def world(self) -> int:
         import torch.distributed as dist
         return dist.get_world_size(self.pg) if (dist.is_available() and dist.is_initialized()) else 1
 
+    def rank(self) -> int:
+        if self._rank is not None:
+            return self._rank
+        import torch.distributed as dist
+        return dist.get_rank(self.pg) if (dist.is_available() and dist.is_initialized()) else 0
+
+    def _rank_seed(self) -> int:
+        """Philox key of this rank: every data-parallel rank must draw DIFFERENT Gumbel noise for its prompts (the
+        kernel's counter is the local (b, g, t)); golden-ratio stride in the 64-bit key space, rank 0 keeps `seed`."""
+        return (self.seed + 0x9E3779B97F4A7C15 * self.rank()) & (2 ** 64 - 1)
+
+    # ---- micro-step ---------------------------------------------------------------------------------------
     def rollout(self, feats, txt, clip, G: int, k: int, tau: float, noise=None):
-        """scores once, G Gumbel-top-k rollouts per prompt in one launch (tspo_trainer.py:508-537)."""
+        """scores once, G Gumbel-top-k rollouts per prompt in one launch (tspo_trainer.py:508-537).
+        Returns (scores [B,T], idx [B,G,k], logp [B,T], ctx) - pass `ctx` to the matching backward()."""
         B, T, D = feats.shape
         need = ops._lib.lib().tspo_selector_workspace_bytes(B, T, D, self.heads, txt.shape[1], self.window)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty((need,), dtype=torch.uint8, device=feats.device)
+        ws = None
+        for i, cand in enumerate(self._ws_pool):
+            if cand.numel() >= need and cand.device == feats.device:
+                ws = self._ws_pool.pop(i)
+                break
+        if ws is None:
+            ws = torch.empty((need,), dtype=torch.uint8, device=feats.device)
         scores, _, _ = ops.selector_forward(self.flat, feats, txt, clip, self.heads, self.window, tau, want_attn=False,
-                                            ws=self._ws, precision=self.gemm_precision)
-        out = ops.gumbel_topk(scores, k, G, noise=noise, seed=self.seed, offset=self.step_no)
-        return scores, out["idx"], out["logp"]
+                                            ws=ws, precision=self.gemm_precision)
+        out = ops.gumbel_topk(scores, k, G, noise=noise, seed=self._rank_seed(), offset=self._rollouts)
+        ctx = RolloutContext(ws, (B, T, D), txt.shape[1], tau, self._param_version, self._rollouts, self)
+        self._rollouts += 1
+        return scores, out["idx"], out["logp"], ctx
 
-    def update(self, feats, txt, logp, idx, rewards, tau: float, lr: Optional[float] = None) -> Dict[str, torch.Tensor]:
-        """advantage -> closed-form dL/dlogits -> selector backward -> all-reduce(mean) -> clip -> AdamW."""
+    def backward(self, ctx: RolloutContext, feats, txt, logp, idx, rewards) -> Dict[str, torch.Tensor]:
+        """advantage -> closed-form dL/dlogits -> selector backward, accumulated into the flat gradient bucket
+        (mean over the micro-steps of this optimizer step, like DeepSpeed's gradient accumulation)."""
+        if not isinstance(ctx, RolloutContext) or ctx.owner is not self:
+            raise TypeError("backward() needs the RolloutContext returned by this trainer's rollout()")
+        if ctx.consumed:
+            raise RuntimeError("this RolloutContext was already used by a backward(); call rollout() again")
+        if ctx.param_version != self._param_version:
+            raise RuntimeError("stale RolloutContext: the parameters changed (optimizer_step) after its rollout()")
+        if tuple(feats.shape) != ctx.shape or txt.shape[1] != ctx.M:
+            raise ValueError(f"backward(): feats {tuple(feats.shape)} / txt M={txt.shape[1]} do not match the rollout "
+                             f"this context belongs to ({ctx.shape}, M={ctx.M})")
+        if self._micro >= self.grad_accum_steps:
+            raise RuntimeError("gradient accumulation boundary reached: call optimizer_step() before another backward()")
         B = feats.shape[0]
         adv = ops.grpo_advantage(rewards)
-        dlog, loss = ops.pg_grad_logits(logp, idx, adv, scale=1.0 / B)
-        ops.selector_backward(self.flat, self.grad, feats, txt, dlog, self.heads, self.window, tau, self._ws,
+        dlog, loss = ops.pg_grad_logits(logp, idx, adv, scale=1.0 / (B * self.grad_accum_steps))
+        if self._micro == 0:
+            target = self.grad
+        else:
+            if self._gmicro is None:
+                self._gmicro = torch.empty_like(self.grad)
+            target = self._gmicro
+        ops.selector_backward(self.flat, target, feats, txt, dlog, self.heads, self.window, ctx.tau, ctx.ws,
                               precision=self.gemm_precision)
-        world = self.world()
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grad[: self.n_train], op=dist.ReduceOp.SUM, group=self.pg)   # RCCL over xGMI
-        ns = ops.grad_norm_scale(self.grad, self.n_train, 1.0 / world, self.max_norm * world)
-        # ^ the bucket holds the SUM over ranks: its norm is world x the norm of the mean gradient, so clipping the
-        #   mean at max_norm == clipping the sum at world*max_norm, then scaling by 1/world.
+        if target is not self.grad:
+            self.grad[: self.n_train].add_(target[: self.n_train])
+        self._micro += 1
+        ctx.consumed = True
+        self._ws_pool.append(ctx.ws)
+        ctx.ws = None
+        return {"loss": loss * self.grad_accum_steps, "advantages": adv}
+
+    def at_boundary(self) -> bool:
+        return self._micro >= self.grad_accum_steps
+
+    def current_lr(self) -> float:
+        return float(self.lr_schedule(self.step_no)) if self.lr_schedule is not None else self.lr
+
+    def optimizer_step(self, lr: Optional[float] = None) -> Dict[str, torch.Tensor]:
+        """all-reduce (sum) of the bucket -> clip-norm of the MEAN gradient -> AdamW, on the accumulation boundary."""
+        if self._micro == 0:
+            raise RuntimeError("optimizer_step() without a backward()")
+        world = int(self.reduce_fn(self.grad, self.n_train, self.pg))      # RCCL over xGMI (one collective)
+        # the bucket now holds the SUM over ranks: its norm is world x the norm of the mean gradient, so clipping the
+        # mean at max_norm == clipping the sum at world*max_norm, then scaling by 1/world (no extra pass over the bucket)
+        ns = ops.grad_norm_scale(self.grad, self.n_train, 1.0 / world, self.max_norm * world, out=self._norm_out,
+                                 ws=self._norm_ws)
+        use_lr = lr if lr is not None else self.current_lr()
         self.step_no += 1
-        ops.adamw_step(self.flat, self.grad, self.m, self.v, self.n_train, lr if lr is not None else self.lr,
-                       self.step_no, self.betas[0], self.betas[1], self.eps, self.wd, 1.0, ns)
-        return {"loss": loss, "advantages": adv, "grad_norm_scale": ns}
+        ops.adamw_step(self.flat, self.grad, self.m, self.v, self.n_train, use_lr, self.step_no, self.betas[0],
+                       self.betas[1], self.eps, self.wd, 1.0, ns)
+        self._micro = 0
+        self._param_version += 1
+        return {"grad_norm_scale": ns, "lr": use_lr, "world": world}
+
+    # ---- one-micro-batch conveniences ---------------------------------------------------------------------
+    def update(self, ctx: RolloutContext, feats, txt, logp, idx, rewards, lr: Optional[float] = None):
+        """backward() and, when that completes the accumulation window, optimizer_step()."""
+        stats = self.backward(ctx, feats, txt, logp, idx, rewards)
+        if self.at_boundary():
+            stats.update(self.optimizer_step(lr))
+        return stats
 
     def step(self, feats, txt, clip, reward_fn: Callable[[torch.Tensor], torch.Tensor], G: int, k: int, tau: float,
              noise=None, lr: Optional[float] = None):
-        scores, idx, logp = self.rollout(feats, txt, clip, G, k, tau, noise)
+        scores, idx, logp, ctx = self.rollout(feats, txt, clip, G, k, tau, noise)
         rewards = reward_fn(idx)                      # [B,G] - the frozen video-LLM pass lives here (stock PyTorch)
-        stats = self.update(feats, txt, logp, idx, rewards, tau, lr)
+        stats = self.update(ctx, feats, txt, logp, idx, rewards, lr)
         stats.update(scores=scores, idx=idx, rewards=rewards)
         return stats
+
+    # ---- optimizer state (save_steps / resume; the reference saves model-only checkpoints, train_deepspeed.sh:41) ----
+    def state_dict(self) -> Dict[str, object]:
+        return {"flat": self.flat.detach().clone(), "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(),
+                "step": self.step_no, "rollouts": self._rollouts, "seed": self.seed, "micro": self._micro,
+                "grad": self.grad.clone() if self._micro else None, "dim": self.dim}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        if int(sd["dim"]) != self.dim:
+            raise ValueError(f"optimizer state is for dim={sd['dim']}, trainer has dim={self.dim}")
+        self.flat.copy_(sd["flat"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.step_no, self._rollouts, self.seed = int(sd["step"]), int(sd["rollouts"]), int(sd["seed"])
+        self._micro = int(sd.get("micro", 0))
+        if self._micro and sd.get("grad") is not None:
+            self.grad.copy_(sd["grad"])
+        self._param_version += 1
 
 
 def annealed_tau(score_tau: float, step: int, max_steps: int) -> float:
     """tspo_trainer.py:496: tau = tau0 - (tau0 - 0.01) / max_steps * step."""
     return score_tau - (score_tau - 0.01) / max_steps * step
+
+
+def linear_decay_lr(base_lr: float, max_steps: int, warmup_steps: int = 0) -> Callable[[int], float]:
+    """HF Trainer's default `lr_scheduler_type="linear"` (what train_deepspeed.sh runs with: lr 5e-4, no warmup):
+    lr(step) = base * step/warmup during warmup, then base * (max_steps - step) / (max_steps - warmup)."""
+    def f(step: int) -> float:
+        if step < warmup_steps:
+            return base_lr * step / max(1, warmup_steps)
+        return base_lr * max(0.0, (max_steps - step) / max(1, max_steps - warmup_steps))
+    return f
