@@ -56,9 +56,10 @@ def _batch(step):
     f = torch.from_numpy(synth.normal((B_GLOBAL, T, D), 100 + step))
     t = torch.from_numpy(synth.normal((B_GLOBAL, 1, D), 200 + step))
     c = torch.stack([O.clip_cosine_scores(t[b], f[b]) for b in range(B_GLOBAL)])
-    u = torch.from_numpy(synth.uniform((B_GLOBAL, G, T), 300 + step)).clamp(1e-6, 1 - 1e-6)
+    u = torch.from_numpy(synth.uniform((B_GLOBAL, G, T), 300 + step).reshape(B_GLOBAL, G, T)).clamp(1e-6, 1 - 1e-6)
     noise = -torch.log(-torch.log(u))
-    rew = torch.from_numpy(synth.uniform((B_GLOBAL, G), 400 + step)).round() + torch.from_numpy(synth.uniform((B_GLOBAL, G), 500 + step))
+    rew = (torch.from_numpy(synth.uniform((B_GLOBAL, G), 400 + step)).round()
+           + torch.from_numpy(synth.uniform((B_GLOBAL, G), 500 + step))).reshape(B_GLOBAL, G)
     return f.float(), t.float(), c.float(), noise.float(), rew.float()
 
 

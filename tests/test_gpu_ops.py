@@ -428,7 +428,7 @@ def test_gemm_bf16_persistent_kernel_full_check(N, K):
         want, kw = ref + R.float(), dict(residual=R.to(DEV))
     else:
         want, kw = ref, {}
-    for variant in (0, 6, 80, 81, 2, 70, 71):     # auto, 256x256 ring, 4-wave AGPR (2x64K, 5x32K rings), 256x128 ring, role-split, 16-wave
+    for variant in (0, 6, 82, 2, 70, 71):     # auto, 8-wave LDS-DMA ring, 4-wave AGPR register-staged, 256x128 ring, role-split, 16-wave
         act = kw.get("act", 0) | (variant << 8)
         out = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=act).float().cpu()
         np.testing.assert_allclose(out.numpy(), want.numpy(), err_msg=f"variant {variant}", **tol)

@@ -22,6 +22,8 @@ shapes = [("qkv", 3072, 1024, 0, False), ("out", 1024, 1024, 0, True), ("fc1", 4
 for name, N, K, act, resid in shapes:
     A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g, device=dev) * 0.03).to(torch.bfloat16)
+    if os.environ.get("TSPO_BENCH_FILL") == "zero":      # power probe: same kernels on zero-filled operands (DVFS)
+        A.zero_(); W.zero_()
     bias = torch.randn(N, generator=g, device=dev) * 0.1
     bias16 = bias.to(torch.bfloat16)
     R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16) if resid else None

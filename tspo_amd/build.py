@@ -10,8 +10,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtspo_hip.so")
-SOURCES = ["sampler.hip", "selector.hip", "gemm_bf16.hip", "clip_vit.hip", "preprocess.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_bf16.h"), os.path.join(os.path.dirname(PKG), "include", "tspo_hip.h")]
+SOURCES = ["sampler.hip", "selector.hip", "gemm_bf16.hip", "gemm_agpr.hip", "clip_vit.hip", "preprocess.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_bf16.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(os.path.dirname(PKG), "include", "tspo_hip.h")]
 
 
 def _hipcc() -> str:

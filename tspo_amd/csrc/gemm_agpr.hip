@@ -1,0 +1,348 @@
+// bf16 MFMA GEMM for gfx950 (MI355X) with ONE wave per SIMD: persistent 256x256x64 tile, four waves (2x2), each wave owning
+// 128x128 outputs = 8x8 MFMA 16x16x32 tiles = 256 fp32 accumulators per lane, held in the accumulator half of the unified
+// register file under LITERAL names a[0:255].  hipcc cannot allocate a 256-accumulator kernel itself (it spills, also with
+// "+a" inline-asm operands - DESIGN 4.1), so every MFMA, accumulator read and zeroing here is an inline-asm statement that
+// names its AGPRs, and hipcc allocates only the architectural VGPRs around them.  Two guards keep it out of a[0:255]:
+// A4_FENCE() statements (empty asm that "clobbers" all 256 AGPRs) between the MFMA groups, so nothing of the compiler's
+// can live in an AGPR across them, and an audit of the generated code (tests/test_abi.py: no scratch access and no
+// AGPR reference outside the asm statements).
+//
+// Operand path ("a7"): buffer_load_dwordx4 -> 64 staging VGPRs per lane -> ds_write_b128 into a 2 x 64 KB LDS ring, NOT
+// LDS-DMA.  Measured (profiles/r2_*): the 8-wave LDS-DMA kernel of gemm_bf16.hip, a 4-wave LDS-DMA kernel with this wave
+// layout (-33 % LDS reads per MFMA) and one with five 32 KB half-stages (96 KB in flight) all run a K-step in ~3600 cycles
+// for ~2200 cycles of MFMA; what they share is 64 LDS-DMA wave-instructions per CU and K-step - an LDS-DMA piece holds up
+// the issuing wave for 60-180 cycles, and the stream tops out near 25 B/clk/CU.  Ordinary vector loads do not pay that, and
+// with the accumulators in AGPRs there are VGPRs to keep a whole K-step share (16 x 16 B per lane) in flight.
+//   piece j (8 rows x 128 B; 0-7 = A, 8-15 = W):  S_j(x) = ds_write_b128 of piece j's registers into stage x's buffer,
+//                                                 G_j(x) = buffer_load_dwordx4 of stage x's rows into the same registers
+//   K-step it:  [A] 64 MFMAs on K-half 0 | fragments of K-half 1 | S_j(it+1), G_j(it+2) for the W pieces | lgkmcnt(0) s_barrier
+//               [B] 64 MFMAs on K-half 1 | fragments of K-half 0 of stage it+1 | S_j(it+2), G_j(it+3) for the A pieces
+// Every load has a full K-step to land before its ds_write; every fragment read half a K-step before its MFMAs; the only
+// synchronisation is one barrier per K-step between four waves running the same in-order stream on separate SIMDs.
+// LDS image as in gemm_bf16.hip: 128-byte rows, 16-byte chunk c of row r at chunk c ^ (r & 7) (here applied by the
+// ds_write address: the 8 lanes of a row cover all 32 banks) -> conflict-free ds_read_b128 fragment reads.
+#include "gemm_epilogue.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+namespace {
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(static_cast<F&&>(f));
+  }
+}
+
+#define A4_ALL_AGPRS                                                                                                     \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18",  \
+      "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35",   \
+      "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52",   \
+      "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69",   \
+      "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86",   \
+      "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102",       \
+      "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117",  \
+      "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132",  \
+      "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147",  \
+      "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162",  \
+      "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177",  \
+      "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192",  \
+      "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207",  \
+      "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222",  \
+      "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237",  \
+      "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252",  \
+      "a253", "a254", "a255"
+
+#define A4_FENCE() asm volatile("" ::: A4_ALL_AGPRS)
+// accumulator tile (nn, mi) = a[(nn*8 + mi)*4 .. +3]; nn = column tile 0..7 (16 columns each), mi = row tile 0..7
+#define A4_MFMA(NN, MI, WF, AF)                                                                              \
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(WF), "v"(AF), "i"(((NN)*8 + (MI)) * 4), \
+               "i"(((NN)*8 + (MI)) * 4 + 3))
+#define A4_MFMA_Z(NN, MI, WF, AF)   /* first K-half of a tile: C = 0, no zeroing pass over the accumulators */     \
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(WF), "v"(AF), "i"(((NN)*8 + (MI)) * 4), \
+               "i"(((NN)*8 + (MI)) * 4 + 3))
+template <int IDX>
+__device__ __forceinline__ float a4_acc_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(IDX));
+  return x;
+}
+
+// What a 64-column slice of the wave's tile needs from memory besides the residual: bias / folded bias, LayerNorm column
+// sums, (rstd, -mean*rstd) of the lane's 8 rows.  Slice 0's copy is fetched one K-step BEFORE the epilogue (behind the
+// MFMAs of the tile's last K-step), slice 1's at the start of the epilogue - so no load latency is exposed for them.
+struct EpiPre { EpiCols ec; float2 rst[8]; };
+template <int EPI>
+__device__ __forceinline__ void epi_prefetch(const GemmArgs& g, int m0, int n0, int wm, int ws, int l15, int q4, EpiPre& p) {
+  constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
+  g3_epi_cols<EPI>(g, n0, ws, q4, p.ec);
+  if (epi_has_bias(EPI)) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + ws * 64 + ni * 16 + q4 * 4;
+      p.ec.bias[ni] = *reinterpret_cast<const f32x4*>(g.bias + (n < g.N ? n : 0));
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) p.rst[mi] = LN ? g3_epi_rowstat(g, m0 + wm * 128 + mi * 16 + l15) : make_float2(1.f, 0.f);
+}
+
+// Epilogue of the wave's 128x128 tile held in a[0:255].  The residual tile comes in 16-byte loads in the STORE mapping
+// (4 lanes cover 64 contiguous bytes of a row) through a ring of 8 x 2 registers: all 8 row blocks of slice 0 are
+// requested up front, and as soon as row block mi of slice 0 has consumed its pair it is re-requested for slice 1, so
+// slice 1's residual arrives behind slice 0's arithmetic; v_permlane16_swap (the inverse of the store-side swap) brings
+// it back to the MFMA layout.
+template <int EPI, bool FULL>
+__device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0, int wm, int wn, int l15, int q4,
+                                              const EpiPre& p0) {
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first v_accvgpr_read
+  constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
+  EpiPre p1;
+  epi_prefetch<EPI>(g, m0, n0, wm, wn * 2 + 1, l15, q4, p1);
+  uint4 rres[8][2];
+  auto rload = [&](int mi, int ws) {
+    const int m = m0 + wm * 128 + mi * 16 + l15;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int n = n0 + ws * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
+      const bool ok = FULL || (m < g.M && n < g.N);
+      rres[mi][pr] = ok ? *reinterpret_cast<const uint4*>(g.R + (size_t)m * g.N + n) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  if (RES) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) rload(mi, wn * 2);
+  }
+  sfor<0, 2>([&](auto nh_) {                          // the wave's two 64-column slices
+    constexpr int nhs = decltype(nh_)::value;
+    const int ws = wn * 2 + nhs;
+    const EpiPre& p = nhs == 0 ? p0 : p1;
+    sfor<0, 8>([&](auto mi_) {
+      constexpr int mi = decltype(mi_)::value;
+      f32x4 vv[4];
+      sfor<0, 4>([&](auto ni_) {
+        constexpr int ni = decltype(ni_)::value;
+        constexpr int base = ((nhs * 4 + ni) * 8 + mi) * 4;
+        vv[ni][0] = a4_acc_read<base>(); vv[ni][1] = a4_acc_read<base + 1>();
+        vv[ni][2] = a4_acc_read<base + 2>(); vv[ni][3] = a4_acc_read<base + 3>();
+      });
+      A4_FENCE();
+      uint2 rp[4] = {};
+      if (RES) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const auto x = __builtin_amdgcn_permlane16_swap(rres[mi][pr].x, rres[mi][pr].z, false, false);
+          const auto y = __builtin_amdgcn_permlane16_swap(rres[mi][pr].y, rres[mi][pr].w, false, false);
+          rp[2 * pr] = make_uint2(x[0], y[0]);
+          rp[2 * pr + 1] = make_uint2(x[1], y[1]);
+        }
+        if (nhs == 0) rload(mi, wn * 2 + 1);
+      }
+      g3_epi_row<EPI, true, FULL>(g, vv, p.ec, p.rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
+    });
+  });
+}
+
+// A2: A staged two K-steps ahead in two register sets (else one set, one K-step ahead).  PRE0: slice 0's small epilogue
+// inputs are requested behind the tile's last K-step (else at the start of the epilogue).  Both cost VGPRs.
+template <int EPI, bool A2, bool PRE0>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int tilesM, int ngrp) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE];  // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int nk = g.K / GT_BK;   // even, >= 2 (the dispatcher sends other shapes to the 8-wave kernel)
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
+  const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
+  const int panels = (tilesM - pset + npset - 1) / npset;
+  const int ntile_x = panels * n_per;
+  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
+  if (my_tiles == 0) return;
+  A4_FENCE();   // claims a[0:255] for this kernel
+
+  // ---- staging registers: this wave's 8 W pieces of a stage (one set, loaded ONE K-step ahead: W is re-read by every
+  //      tile and lives in L2) and its 8 A pieces in TWO sets, loaded TWO K-steps ahead: every K-step's A slice is a
+  //      first touch of HBM data whose latency under load exceeds a K-step - with one set the ds_write of every K-step
+  //      waited for it (and loads return in order, so everything behind it waited too) ----
+  const int rin = lane >> 3, slot = lane & 7;
+  const unsigned lane_goff = ((unsigned)rin * (unsigned)g.K + (unsigned)(slot << 3)) * 2u;   // plain 128-byte rows
+  const int lane_woff = rin * 128 + ((slot ^ rin) << 4);                                      // swizzled LDS image
+  const unsigned piece_stride = 8u * (unsigned)g.K * 2u;
+  u32x4 sa0[8], sa1[8], sw_[8];
+  // the stage the A registers / the W registers are loaded for NEXT: K-step inside the tile, tile, resource descriptor
+  // (rows past the matrix end - and whole tiles past the last one - fall outside num_records and read as zeros)
+  int a_kt = 0, a_s = wl, w_kt = 0, w_s = wl;
+  auto rsrc_a = [&](int s_) {
+    const int m0 = ((s_ / n_per) * npset + pset) * G3_BM;
+    const long r = m0 < g.M ? ((long)(g.M - m0) * g.K * 2) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)(m0 < g.M ? m0 : 0) * g.K), 0,
+                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
+  };
+  auto rsrc_w = [&](int s_) {
+    const int n0 = (grp * n_per + s_ % n_per) * G3_BN;
+    const long r = n0 < g.N ? ((long)(g.N - n0) * g.K * 2) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)(n0 < g.N ? n0 : 0) * g.K), 0,
+                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t a_rs = rsrc_a(a_s), w_rs = rsrc_w(w_s);
+  auto adv_a = [&]() { if (++a_kt == nk) { a_kt = 0; a_s += nwl; a_rs = rsrc_a(a_s); } };
+  auto adv_w = [&]() { if (++w_kt == nk) { w_kt = 0; w_s += nwl; w_rs = rsrc_w(w_s); } };
+  auto gload_a = [&](auto q_, u32x4 (&sa)[8]) {
+    constexpr int q = decltype(q_)::value;
+    sa[q] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, lane_goff + (unsigned)a_kt * (GT_BK * 2u),
+                                                  (unsigned)(wid * 8 + q) * piece_stride, 0);
+  };
+  auto gload_w = [&](auto q_) {
+    constexpr int q = decltype(q_)::value;
+    sw_[q] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane_goff + (unsigned)w_kt * (GT_BK * 2u),
+                                                   (unsigned)(wid * 8 + q) * piece_stride, 0);
+  };
+  auto swrite_a = [&](auto q_, const u32x4 (&sa)[8], int buf) {
+    constexpr int q = decltype(q_)::value;
+    *reinterpret_cast<u32x4*>(lds + buf * G3_STAGE + (wid * 8 + q) * 1024 + lane_woff) = sa[q];
+  };
+  auto swrite_w = [&](auto q_, int buf) {
+    constexpr int q = decltype(q_)::value;
+    *reinterpret_cast<u32x4*>(lds + buf * G3_STAGE + G3_BM * 128 + (wid * 8 + q) * 1024 + lane_woff) = sw_[q];
+  };
+
+  // ---- prologue: stage 0 complete in buffer 0; A of stage 1 in buffer 1, W of stage 1 in the W registers; A of stages
+  //      2 and 3 in A register sets 0 and 1 ----
+  sfor<0, 8>([&](auto q_) { gload_a(q_, sa0); gload_w(q_); });
+  sfor<0, 8>([&](auto q_) { swrite_a(q_, sa0, 0); swrite_w(q_, 0); });
+  adv_a(); adv_w();
+  sfor<0, 8>([&](auto q_) { gload_a(q_, sa0); gload_w(q_); });
+  sfor<0, 8>([&](auto q_) { swrite_a(q_, sa0, 1); });
+  adv_a(); adv_w();   // w cursor -> stage 2 (loaded in [A] of K-step 0, after stage 1's W went to LDS)
+  sfor<0, 8>([&](auto q_) { gload_a(q_, sa0); });
+  adv_a();
+  if (A2) {
+    sfor<0, 8>([&](auto q_) { gload_a(q_, sa1); });
+    adv_a();
+  }
+
+  // ---- fragments: A double-buffered per K-half (2 x 32 VGPRs); W in ONE set of 8 x 4 VGPRs refilled in place: the
+  //      fragment of column tile nn is dead after its 8 MFMAs, so the next K-half's fragment nn is read right behind them ----
+  const int sw = l15 & 7;
+  const int fbaseA = (wm * 128 + l15) * 128, fbaseW = G3_BM * 128 + (wn * 128 + l15) * 128;
+  i32x4 fa0[8], fa1[8], fw[9];   // fw[8]: spare slot of the last column tile (see khalf)
+  auto co_of = [&](int kk) { return ((kk * 4 + q4) ^ sw) << 4; };
+  auto read_a = [&](const char* buf, int kk, i32x4 (&fa)[8]) {
+    const int co = co_of(kk);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const i32x4*>(buf + fbaseA + i * 2048 + co);
+  };
+  auto read_w_all = [&](const char* buf, int kk) {
+    const int co = co_of(kk);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fw[i] = *reinterpret_cast<const i32x4*>(buf + fbaseW + i * 2048 + co);
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  read_a(lds, 0, fa0);
+  read_w_all(lds, 0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+
+  // one K-half: 64 MFMAs on (fa, fw); behind column tile nn's MFMAs its W fragment is refilled from (nbuf, nkk) = the next
+  // K-half; na <- the next K-half's A fragments behind the first 16 MFMAs; one staging piece behind every 6th MFMA from
+  // the 17th on: its registers go to LDS (ring buffer sbuf) and are reloaded for the cursor's stage
+  // The W fragment of the LAST column tile cannot be refilled behind its own MFMAs - the read would be the last thing
+  // before the barrier's lgkmcnt(0) and expose a full LDS latency every K-half - so it alternates between slots 7 and 8
+  // (PAR = parity of the K-half: [A] computes from slot 7 and fills slot 8 early, [B] the other way round).
+  auto khalf = [&](auto zero_, auto par_, i32x4 (&fa)[8], i32x4 (&na)[8], const char* nbuf, int nkk, auto&& piece) {
+    constexpr bool ZERO = decltype(zero_)::value;
+    constexpr int PAR = decltype(par_)::value;
+    const int wco = co_of(nkk);
+    sfor<0, 8>([&](auto nn_) {
+      constexpr int nn = decltype(nn_)::value;
+      constexpr int slot = nn == 7 ? 7 + PAR : nn;
+      if (nn == 2) read_a(nbuf, nkk, na);
+      sfor<0, 8>([&](auto mi_) {
+        constexpr int mi = decltype(mi_)::value;
+        if (nn >= 2 && (nn * 8 + mi - 16) % 6 == 0) piece(std::integral_constant<int, (nn * 8 + mi - 16) / 6>{});
+        const i32x4 wf = fw[slot], af = fa[mi];
+        if (ZERO) A4_MFMA_Z(nn, mi, wf, af); else A4_MFMA(nn, mi, wf, af);
+      });
+      if (nn < 7) fw[nn] = *reinterpret_cast<const i32x4*>(nbuf + fbaseW + nn * 2048 + wco);
+      if (nn == 4) fw[8 - PAR] = *reinterpret_cast<const i32x4*>(nbuf + fbaseW + 7 * 2048 + wco);
+      A4_FENCE();
+    });
+  };
+
+  int it = 0, c_s = wl;
+  auto kstep = [&](auto zero_, u32x4 (&sa)[8]) {
+    const int cb = it & 1, nb = cb ^ 1;
+    const char* cur = lds + cb * G3_STAGE;
+    const char* nxt = lds + nb * G3_STAGE;
+    // [A]: K-half 0; fragments of K-half 1 of this stage; W pieces: S_j(it+1) -> buffer nb, then G_j(it+2)
+    khalf(zero_, std::integral_constant<int, 0>{}, fa0, fa1, cur, 1, [&](auto j_) { swrite_w(j_, nb); gload_w(j_); });
+    adv_w();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage it+1 complete in LDS; buffer cb fully read
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // (the same wait as a builtin: free at run time, keeps hipcc's wait model exact)
+    // [B]: K-half 1; fragments of K-half 0 of stage it+1; A pieces of set `sa`: S_j(it+2) -> buffer cb, then G_j(it+4)
+    khalf(std::false_type{}, std::integral_constant<int, 1>{}, fa1, fa0, nxt, 0, [&](auto j_) { swrite_a(j_, sa, cb); gload_a(j_, sa); });
+    adv_a();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    ++it;
+  };
+  for (int t = 0; t < my_tiles; ++t) {   // nk even: K-step kt of a tile always uses A register set kt & 1
+    const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
+    kstep(std::true_type{}, sa0);                              // first K-step: its K-half 0 starts the accumulators (C = 0)
+    for (int kt = 1; kt < nk - 1; kt += 2) {
+      kstep(std::false_type{}, A2 ? sa1 : sa0);
+      kstep(std::false_type{}, sa0);
+    }
+    EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
+    if (PRE0) epi_prefetch<EPI>(g, m0, n0, wm, wn * 2, l15, q4, p0);
+    kstep(std::false_type{}, A2 ? sa1 : sa0);
+    if (!PRE0) epi_prefetch<EPI>(g, m0, n0, wm, wn * 2, l15, q4, p0);
+    if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
+    else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
+    c_s += nwl;
+    // the next tile's first fragments again, AFTER the epilogue: the copies read in the last [B] are dead here, so
+    // nothing but the staging registers stays live across the epilogue (stale data after the last tile, never used)
+    const char* nbuf = lds + (it & 1) * G3_STAGE;
+    read_a(nbuf, 0, fa0);
+    read_w_all(nbuf, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+}
+
+template <int EPI, bool A2, bool PRE0>
+int launch_gemm_a7(GemmArgs g, hipStream_t st) {
+  const int tilesM = (g.M + G3_BM - 1) / G3_BM;
+  g.tilesN = (g.N + G3_BN - 1) / G3_BN;
+  g.nwg = tilesM * g.tilesN;
+  int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
+  if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
+  hipLaunchKernelGGL((gemm_bf16_a7_kernel<EPI, A2, PRE0>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
+  return tspo::check_launch("gemm_bf16_a7");
+}
+}  // namespace
+
+namespace {
+template <int EPI>
+int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
+  if ((g.K / GT_BK) % 2 != 0 || g.K < 2 * GT_BK)
+    return tspo::set_err(TSPO_EINVAL, "gemm_agpr: K=%d must be a multiple of 128", g.K);
+  if (g.variant == 83) return launch_gemm_a7<EPI, true, false>(g, st);    // A/B: A two K-steps ahead, no early epilogue prefetch
+  return launch_gemm_a7<EPI, false, true>(g, st);
+}
+}  // namespace
+
+int tspo::gemm_bf16_agpr(int epi, const GemmArgs& g, hipStream_t st) {
+  switch (epi) {
+    case GE_BIAS: return launch_a7_variant<GE_BIAS>(g, st);
+    case GE_GELU: return launch_a7_variant<GE_GELU>(g, st);
+    case GE_RESID: return launch_a7_variant<GE_RESID>(g, st);
+    case GE_F32: return launch_a7_variant<GE_F32>(g, st);
+    case GE_PATCH: return launch_a7_variant<GE_PATCH>(g, st);
+    case GE_BIAS_LN: return launch_a7_variant<GE_BIAS_LN>(g, st);
+    case GE_GELU_LN: return launch_a7_variant<GE_GELU_LN>(g, st);
+    case GE_RESID_ST: return launch_a7_variant<GE_RESID_ST>(g, st);
+  }
+  return tspo::set_err(TSPO_EINVAL, "gemm_agpr: bad epilogue %d", epi);
+}

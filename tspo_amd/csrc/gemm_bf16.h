@@ -26,4 +26,6 @@ namespace tspo {
 int gemm_bf16(int epi, const GemmArgs& g, hipStream_t st);
 // true when gemm_bf16 would run this shape on the persistent 256x256 kernel (the only one with the *_LN / *_ST epilogues)
 bool gemm_bf16_is_big(long M, int N, int K);
+// gemm_agpr.hip: the 4-wave kernels that keep 256 accumulators per lane in AGPRs (g.variant selects the kernel)
+int gemm_bf16_agpr(int epi, const GemmArgs& g, hipStream_t st);
 }
