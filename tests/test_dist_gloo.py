@@ -35,7 +35,10 @@ def _worker(rank, world, port, q):
     for b in shard:                                                  # per-prompt "gradients"
         bucket[:n] += torch.from_numpy(synth.normal((n,), 1000 + b))
     bucket[n:] = 7.0                                                 # ffn_o region must not be touched
-    td.allreduce_mean_(bucket, n)
+    summed = bucket.clone()
+    assert td.allreduce_bucket_(summed, n) == world          # THE exchange PolicyTrainer.optimizer_step issues (sum kept)
+    td.allreduce_mean_(bucket, n)                             # = allreduce_bucket_(average=True)
+    assert torch.allclose(summed[:n] / world, bucket[:n], rtol=1e-6, atol=1e-7) and torch.equal(summed[n:], bucket[n:])
     metrics = td.reduce_metrics(td.pack_metrics(
         dict(ts_length=16, completion_length=10 + rank, reward=0.5 * rank, advantages=0.0, reward_mean=rank, reward_std=1.0),
         [1.0 * rank, 0.25]), 2, ["accuracy_reward", "temporal_localization_reward"])

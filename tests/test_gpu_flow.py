@@ -1,0 +1,203 @@
+"""GPU tests of the flows either side of the hot path: HF entry points on the HIP-backed TSPOModel, the
+evaluation harness's generate_inner flow (cache miss / hit, bf16, T <= 64 skip, VideoMME -> bin-max), weight caches
+under in-place updates, the needle-in-haystack builder feeding the temporal reward in a policy step, and the training
+driver (gradient accumulation, LR decay, tau annealing, JSONL metrics, checkpoint + resume)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tspo_oracle as O
+from tspo_amd import haystack, io as tio, ops, rewards, synth
+from tspo_amd.pipeline import PolicyTrainer
+from tspo_amd.temporal_agent import MultiModal_Align, TSPOModel, invalidate_packed_clip
+from test_gpu_api import _StubProcessor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T_(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def _tiny_cfg():
+    from transformers import CLIPConfig
+    return CLIPConfig(text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                       vocab_size=49408, max_position_embeddings=77, projection_dim=768),
+                      vision_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                         image_size=224, patch_size=14, projection_dim=768), projection_dim=768)
+
+
+def _tiny_model(seed=0):
+    torch.manual_seed(seed)
+    model = TSPOModel(_tiny_cfg()).float().eval()
+    for p in model.vision_model.parameters():
+        if p.ndim >= 2:
+            torch.nn.init.normal_(p, std=0.05)
+    model.selector.load_state_dict({k: T_(v) for k, v in synth.selector_state(768, seed=2, std=0.02).items()})
+    return model
+
+
+def test_from_pretrained_roundtrip_forward_on_gpu(tmp_path):
+    """save_pretrained -> from_pretrained(attn_implementation="flash_attention_2", torch_dtype=bf16, device_map="auto")
+    (gen_id_tspo.py:55): the reloaded model sits on the GPU in bf16 and `forward` returns exactly what the model that was
+    saved returns."""
+    model = _tiny_model().to(torch.bfloat16).to(DEV)
+    frames = synth.uniform_u8((72, 240, 320, 3), 91)
+    proc = _StubProcessor()
+    ids0, pred0 = model(proc, frames, "what is shown?", sample_num=8, window_size=12, method="topk")
+    model.save_pretrained(str(tmp_path / "m"))
+    back = TSPOModel.from_pretrained(str(tmp_path / "m"), attn_implementation="flash_attention_2", torch_dtype=torch.bfloat16,
+                                     device_map="auto")
+    assert back.device.type == "cuda" and back.dtype == torch.bfloat16
+    ids1, pred1 = back(proc, frames, "what is shown?", sample_num=8, window_size=12, method="topk")
+    assert torch.equal(ids0, ids1) and torch.equal(pred0, pred1)
+    assert ids1.dtype == torch.int64 and pred1.dtype == torch.bfloat16 and pred1.shape == (72,)
+
+
+@pytest.mark.parametrize("dataset", ["VideoMME", "MLVU"])
+def test_generate_inner_flow_cache_miss_and_hit(tmp_path, dataset):
+    """mp_tools/vlmeval/vlm/gen_id_tspo.py:59-92 with the real HIP TSPOModel (bf16, as the harness loads it): miss ->
+    extract_feature -> .pth cache; hit -> same ids; the float frame numbers == the oracle's selection (bin-max for VideoMME,
+    top-k otherwise) on the cached features; videos of <= 64 frames are returned whole."""
+    model = _tiny_model(1).to(torch.bfloat16).to(DEV)
+    T = 150
+    frames = synth.uniform_u8((T, 224, 224, 3), 17)
+    sampled_idx = torch.arange(0, 30 * T, 30)                       # absolute frame numbers at 1 fps of a 30 fps video
+    calls = []
+
+    def load_video(path, max_frames_num, fps, force_sample):        # decord stand-in
+        calls.append(path)
+        n = 40 if "short" in path else T
+        return frames[:n], None, None, sampled_idx[:n]
+
+    gen = tio.FrameIdGenerator(model, _StubProcessor(), str(tmp_path), sample_num=64, load_video=load_video)
+    msg = [{"value": "long.mp4"}, {"value": "<image>\nQuestion: what is shown?\nOptions:\nA. a\nB. b"}]
+    ids_miss = gen.generate_inner(msg, index=7, dataset=dataset)
+    assert gen.cache_misses == 1 and calls == ["long.mp4"]
+    stat = torch.load(tio.feature_cache_path(str(tmp_path), dataset, 7))
+    assert sorted(stat) == ["clip_scores", "image", "sampled_idx", "text"] and stat["image"].dtype == torch.bfloat16
+    assert stat["image"].shape == (T, 768) and stat["image"].device.type == "cpu"
+    ids_hit = gen.generate_inner(msg, index=7, dataset=dataset)
+    assert gen.cache_hits == 1 and calls == ["long.mp4"] and ids_hit == ids_miss
+    assert len(ids_hit) == 64 and all(isinstance(x, float) for x in ids_hit) and ids_hit == sorted(ids_hit)
+    # oracle selection on the cached (bf16) features
+    sel = {k: v.detach().float().cpu() for k, v in model.selector.state_dict().items()}
+    s_ref, _ = O.selector_forward(sel, stat["image"].float(), stat["text"].float(), stat["clip_scores"].float(), 12, 0.025)
+    s_ref = s_ref.to(torch.bfloat16).float()                        # the model returns scores in its dtype (bf16)
+    pick = O.binmax(s_ref, 64) if dataset == "VideoMME" else O.topk_sorted(s_ref, 64)
+    want = sampled_idx[pick].float().tolist()
+    got_scores = model.temporal_sampling(stat["image"].to(DEV), stat["text"].to(DEV), stat["clip_scores"].to(DEV),
+                                         "topk", 12, 64)[1].float().cpu()
+    if torch.equal(got_scores, s_ref):                               # identical bf16 scores -> identical selection
+        assert ids_hit == want
+    else:                                                            # (bf16 rounding of near-equal scores may differ by 1 ulp)
+        assert len(set(ids_hit) & set(want)) >= 60
+    # T <= sample_num: no selection, the sampled frame numbers themselves
+    short = gen.generate_inner([{"value": "short.mp4"}, msg[1]], index=8, dataset=dataset)
+    assert short == sampled_idx[:40].float().tolist()
+
+
+def test_weight_caches_see_in_place_updates():
+    m = MultiModal_Align(dim=64, num_heads=8).to(DEV)
+    m.load_state_dict({k: T_(v) for k, v in synth.selector_state(64, seed=4, std=0.1, bias_std=0.05).items()})
+    img, txt, clip = (T_(synth.normal(s, i)).to(DEV) for i, s in enumerate([(40, 64), (1, 64), (40,)], 70))
+    with torch.no_grad():
+        s0, _ = m(img, txt, clip, window_size=12)
+    # training mode (grad enabled): a write through p.data (what DeepSpeed / EMA do) is seen by the very next forward
+    m.mlp[2].weight.data.mul_(0.0)
+    s1, _ = m(img, txt, clip, window_size=12)
+    assert not torch.allclose(s1.detach(), s0)
+    # inference mode caches the packed copy: out-of-band writes need invalidate_packed(), versioned writes do not
+    with torch.no_grad():
+        s2, _ = m(img, txt, clip, window_size=12)
+        assert torch.equal(s2, s1.detach())
+        m.mlp[2].bias.data.add_(1.0)
+        m.invalidate_packed()
+        s3, _ = m(img, txt, clip, window_size=12)
+        assert not torch.equal(s3, s2)
+        m.mlp[2].bias.add_(1.0)                                    # in-place op on the parameter: bumps _version
+        s4, _ = m(img, txt, clip, window_size=12)
+        assert not torch.equal(s4, s3)
+    # flat mode: gradient views survive zero_grad(set_to_none=True) and an optimizer's zero_grad()
+    m2 = MultiModal_Align(dim=64, num_heads=8).to(DEV)
+    m2.load_state_dict({k: T_(v) for k, v in synth.selector_state(64, seed=4, std=0.1, bias_std=0.05).items()})
+    m2.flatten_parameters()
+    opt = torch.optim.SGD(m2.parameters(), lr=0.1)
+    for zero in (lambda: m2.zero_grad(set_to_none=True), lambda: opt.zero_grad(set_to_none=True)):
+        zero()
+        s, _ = m2(img, txt, clip, window_size=12)
+        s.sum().backward()
+        base, n = m2._flat_grad.data_ptr(), m2._flat_grad.numel()
+        for name, p in m2.named_parameters():
+            assert p.grad is not None and base <= p.grad.data_ptr() < base + 4 * n, name
+        assert float(m2._flat_grad.abs().sum()) > 0
+    # packed CLIP weights follow load_state_dict on the vision tower
+    model = _tiny_model(3).to(DEV)
+    px = T_(synth.uniform_u8((4, 3, 224, 224), 5)).to(DEV)
+    f0 = model.extract_feature_from_pixels(px, torch.zeros(1, 768, device=DEV))[0].clone()
+    sd = {k: v * 0.5 for k, v in model.vision_model.state_dict().items()}
+    model.vision_model.load_state_dict(sd)
+    f1 = model.extract_feature_from_pixels(px, torch.zeros(1, 768, device=DEV))[0]
+    assert not torch.allclose(f0, f1)
+    invalidate_packed_clip(model)
+    assert torch.equal(model.extract_feature_from_pixels(px, torch.zeros(1, 768, device=DEV))[0], f1)
+
+
+def test_policy_step_on_needle_in_haystack_sample():
+    """tspo_trainer.py:462-482 + :554-573 end to end on device: true clips of the question's video mixed with distractor
+    clips (seeded like the reference), frames -> HIP CLIP features, G rollouts, temporal reward from `shuffle_mask`
+    (batched on the GPU == the reference's per-rollout host loop), specific-type reward combination, one policy step."""
+    model = _tiny_model(5).to(DEV)
+    L, G, k = 64, 4, 8
+    video = T_(synth.uniform_u8((L, 224, 224, 3), 31)).to(DEV)
+    wrong = haystack.synthetic_distractors(3, 20, video, seed=9)
+    mixed, mask = haystack.build_specific_sample(video, wrong, repeat_times=2, sample_len=20, rng=np.random.RandomState(3))
+    assert mixed.is_cuda and mixed.shape == (100, 224, 224, 3) and int(mask.sum()) == 40
+    feats, text, clip = model.extract_feature(_StubProcessor(), mixed, "where is the cat?")
+    flat = model.selector.flatten_parameters()
+    tr = PolicyTrainer(flat, dim=768, heads=8, window_size=12)
+    f, t, c = feats.float()[None], text.float()[:1][None], clip.float()[None]
+    scores, idx, logp, ctx = tr.rollout(f, t, c, G, k, 0.025)
+    temporal = rewards.selection_mask_reward_gpu(idx, mask.to(DEV)[None])
+    host = rewards.temporal_localization_reward(None, None, [(i, i) for i in idx[0]], mask)
+    np.testing.assert_allclose(temporal[0].cpu().numpy(), np.array(host), atol=1e-7)
+    acc = (temporal > 0.4).float()
+    rew = rewards.combine_rewards(torch.stack([acc, temporal], -1).reshape(G, 2), "specific").reshape(1, G)
+    before = flat.clone()
+    st = tr.update(ctx, f, t, logp, idx, rew)
+    assert torch.isfinite(tr.flat).all() and "grad_norm_scale" in st
+    if float(rew.std()) > 0:
+        assert not torch.equal(tr.flat, before)
+    adv_ref = O.grpo_advantage(rew.cpu().flatten(), G)
+    np.testing.assert_allclose(st["advantages"].cpu().flatten().numpy(), adv_ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_training_driver_accumulation_logging_checkpoint_resume(tmp_path):
+    from tspo_amd import train as tt
+    kw = dict(max_steps=6, num_generations=4, training_sample_len=8, gradient_accumulation_steps=2, save_steps=2,
+              save_total_limit=2, dim=64, heads=8, seed=11)
+    data = lambda: tt.SyntheticFeatures(T=96, D=64, seed=11, device=DEV)
+    cfg_a = tt.TrainConfig(output_dir=str(tmp_path / "a"), **kw)
+    ma = tt.train(cfg_a, data(), resume=False)
+    lines = [json.loads(l) for l in open(os.path.join(cfg_a.output_dir, "metrics.jsonl"))]
+    assert [l["step"] for l in lines] == [1, 2, 3, 4, 5, 6]
+    assert abs(lines[0]["learning_rate"] - 5e-4) < 1e-12 and abs(lines[3]["learning_rate"] - 5e-4 * 3 / 6) < 1e-12   # linear decay
+    assert abs(lines[2]["score_tau"] - (0.025 - (0.025 - 0.01) / 6 * 2)) < 1e-12                                    # tau annealing
+    for key in ("reward", "reward_std", "advantages", "ts_length", "rewards/accuracy_reward",
+                "rewards/temporal_localization_reward", "loss", "grad_norm"):
+        assert key in lines[-1], key
+    assert sorted(os.listdir(cfg_a.output_dir)) == ["checkpoint-4", "checkpoint-6", "metrics.jsonl"]                # save_total_limit 2
+    ck = tio.load_selector_safetensors(os.path.join(cfg_a.output_dir, "checkpoint-6", "model.safetensors"))
+    offs = ops.flat_offsets(64)
+    for name, (o, shape) in offs.items():
+        if not name.startswith("__"):
+            assert torch.equal(ck[name].to(DEV), ma["flat"][o:o + int(np.prod(shape))].view(shape)), name
+    # interrupted after step 4, resumed: identical parameters to the uninterrupted run
+    cfg_b = tt.TrainConfig(output_dir=str(tmp_path / "b"), **kw)
+    tt.train(cfg_b, data(), resume=False, stop_after=4)
+    mb = tt.train(cfg_b, data(), resume=True)
+    assert torch.equal(mb["flat"], ma["flat"])

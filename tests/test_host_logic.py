@@ -154,3 +154,77 @@ def test_reference_import_aliases():
     from model.temporal_agent import TSPOModel as T2, MultiModal_Align as M2    # the reference's import path
     from model.utils import gumbel_softmax as g2
     assert T2 is TSPOModel and M2 is MultiModal_Align and g2 is gumbel_softmax
+
+
+def _tiny_clip_config():
+    from transformers import CLIPConfig
+    return CLIPConfig(text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                       vocab_size=49408, max_position_embeddings=77, projection_dim=768),
+                      vision_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                         image_size=224, patch_size=14, projection_dim=768), projection_dim=768)
+
+
+def test_hf_entry_points_and_merge_flow(tmp_path):
+    """The calls the reference's callers make: gen_id_tspo.py:55 (`from_pretrained(path, attn_implementation=
+    "flash_attention_2", torch_dtype=torch.bfloat16, device_map="auto")` - flash_attn is not installed in the ROCm image)
+    and scripts/merge_weights.py:14-58 (selector tensors out of the last of four training shards ->
+    from_merged_components -> save_pretrained -> reload)."""
+    from safetensors.torch import save_file
+    torch.manual_seed(0)
+    model = TSPOModel(_tiny_clip_config())
+    sel = {k: torch.from_numpy(v) for k, v in synth.selector_state(768, seed=5, std=0.02, bias_std=0.01).items()}
+    model.selector.load_state_dict(sel)
+    d1 = tmp_path / "tspo"
+    model.save_pretrained(str(d1))
+    back = TSPOModel.from_pretrained(str(d1), attn_implementation="flash_attention_2", torch_dtype=torch.bfloat16,
+                                     device_map="auto")
+    assert isinstance(back, TSPOModel) and back.dtype == torch.bfloat16 and isinstance(back.selector, MultiModal_Align)
+    sd1, sd2 = model.state_dict(), back.state_dict()
+    assert sorted(sd1) == sorted(sd2) and len([k for k in sd2 if k.startswith("selector.")]) == 12
+    assert all(torch.equal(sd1[k].to(torch.bfloat16), sd2[k]) for k in sd1)
+
+    # a DeepSpeed-style training checkpoint: four shards, the selector ("multiModal_align.*") in the last one
+    shards = tmp_path / "train_ckpt"
+    shards.mkdir()
+    for i in range(1, 5):
+        st = {f"model.layers.{i}.dummy.weight": torch.randn(4, 4)}
+        if i == 4:
+            st.update({tio.TRAIN_PREFIX + k: v.clone() for k, v in sel.items()})
+        save_file(st, str(shards / f"model-0000{i}-of-00004.safetensors"))
+    from transformers import CLIPModel
+    clip_model = CLIPModel(_tiny_clip_config()).to(torch.bfloat16)
+    module_state_dict = tio.load_selector_safetensors(str(shards / "model-00004-of-00004.safetensors"))
+    assert sorted(module_state_dict) == sorted(sel)
+    merged = TSPOModel.from_merged_components(clip_model=clip_model, selector_state_dict=module_state_dict)
+    assert merged.dtype == torch.bfloat16
+    d2 = tmp_path / "TSPO-0.4B"
+    merged.save_pretrained(str(d2))
+    again = TSPOModel.from_pretrained(str(d2), attn_implementation="flash_attention_2", torch_dtype=torch.bfloat16,
+                                      device_map="auto")
+    for k, v in sel.items():
+        assert torch.equal(again.selector.state_dict()[k], v.to(torch.bfloat16))
+    for k, v in clip_model.state_dict().items():
+        assert torch.equal(again.state_dict()[k], v)
+    assert sorted(tio.extract_selector_state(again.state_dict())) == sorted(sel)      # "selector." prefix of the merged model
+
+
+def test_frame_idx_join_and_pickle(tmp_path):
+    """mp_tools/change_score_tch.py:22-44: results pickle {index: [float]} joined into the annotation list on
+    `question_id` (VideoMME, MLVU) / `id` (LongVideoBench); unknown datasets raise like the reference."""
+    assert tio.join_key("VideoMME") == "question_id" and tio.join_key("mlvu") == "question_id"
+    assert tio.join_key("LongVideoBench") == "id"
+    with pytest.raises(NotImplementedError):
+        tio.join_key("LVBench")
+    res = {"q1": [0.0, 30.0, 60.5], 17: [5, 9]}
+    pk = tmp_path / "work_dir" / "run_VideoMME_supp.pkl"
+    tio.save_results_pickle(res, str(pk))
+    assert tio.load_results_pickle(str(pk)) == {"q1": [0.0, 30.0, 60.5], 17: [5.0, 9.0]}
+    anno = [{"question_id": "q1", "video": "a.mp4"}, {"question_id": "q2", "video": "b.mp4"}]
+    out = tio.frame_idx_json_path(str(tmp_path), "run", "VideoMME")
+    assert out.endswith(os.path.join("jsons_idx", "run_VideoMME_frameIdx.json"))
+    assert tio.write_frame_idx_json(anno, tio.load_results_pickle(str(pk)), out, dataset="VideoMME") == 1
+    docs = json.load(open(out))
+    assert docs[0]["frame_idx"] == [0.0, 30.0, 60.5] and "frame_idx" not in docs[1] and docs[1]["video"] == "b.mp4"
+    anno2 = [{"id": 17}, {"id": 18}]
+    assert tio.write_frame_idx_json(anno2, tio.load_results_pickle(str(pk)), str(tmp_path / "l.json"), dataset="LongVideoBench") == 1
+    assert tio.FrameIdGenerator.problem_of("<image>\nQuestion: what happens?\nOptions:\nA. x") == "what happens?"

@@ -12,7 +12,8 @@ from __future__ import annotations
 
 import json
 import os
-from typing import Dict, Iterable, List, Optional
+import pickle
+from typing import Callable, Dict, Iterable, List, Optional
 
 import torch
 
@@ -37,6 +38,7 @@ def save_feature_cache(path: str, image, text, clip_scores, sampled_idx) -> None
 
 
 def load_feature_cache(path: str, device=None, dtype=None):
+    """gen_id_tspo.py:74-79: tensors go `.to(device).to(dtype)` of the model; sampled_idx stays on the host."""
     stat = torch.load(path, map_location="cpu")
     img, txt, clip, idx = stat["image"], stat["text"], stat["clip_scores"], stat["sampled_idx"]
     if device is not None:
@@ -58,8 +60,38 @@ def select_frame_ids(model, image, text, clip_scores, sampled_idx, dataset: str,
     return abs_ids.float().tolist()
 
 
-def write_frame_idx_json(docs: Iterable[dict], results: Dict, out_path: str, key: str = "index") -> int:
-    """Adds "frame_idx" to every doc whose `key` is in results ({index: [float,...]}) and writes the JSON list."""
+# mp_tools/change_score_tch.py:22-38: annotation file and the field the per-sample results are joined on
+DATASET_JSON = {"VideoMME": "videomme", "LongVideoBench": "lvb_val", "MLVU": "mlvu"}
+DATASET_JOIN_KEY = {"VideoMME": "question_id", "MLVU": "question_id", "LongVideoBench": "id"}
+
+
+def join_key(dataset: str) -> str:
+    """Field of an annotation entry that identifies a sample of `dataset` (change_score_tch.py:33-38)."""
+    for name, key in DATASET_JOIN_KEY.items():
+        if name.lower() == dataset.lower():
+            return key
+    raise NotImplementedError(f"join key of dataset {dataset!r}: to be implemented")   # the reference raises the same
+
+
+def load_results_pickle(path: str) -> Dict:
+    """`work_dir/{name}_{data}_supp.pkl` of the harness: {index: [float absolute frame numbers]} (change_score_tch.py:30-31)."""
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
+def save_results_pickle(results: Dict, path: str) -> None:
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "wb") as f:
+        pickle.dump({k: [float(x) for x in v] for k, v in results.items()}, f)
+
+
+def write_frame_idx_json(docs: Iterable[dict], results: Dict, out_path: str, key: Optional[str] = None,
+                         dataset: Optional[str] = None) -> int:
+    """change_score_tch.py:33-44: adds "frame_idx" to every annotation entry whose join key (by `dataset`, or the explicit
+    `key`) is in `results` ({index: [float,...]}, e.g. from load_results_pickle) and writes the JSON list; entries
+    without a result are kept unchanged (the reference prints their index and continues).  Returns the number joined."""
+    if key is None:
+        key = join_key(dataset) if dataset is not None else "index"
     out, n = [], 0
     for d in docs:
         d = dict(d)
@@ -71,6 +103,49 @@ def write_frame_idx_json(docs: Iterable[dict], results: Dict, out_path: str, key
     with open(out_path, "w") as f:
         json.dump(out, f)
     return n
+
+
+def frame_idx_json_path(base_anno_path: str, name: str, dataset: str) -> str:
+    """change_score_tch.py:27: evaluation/jsons_idx/{name}_{data}_frameIdx.json"""
+    return os.path.join(base_anno_path, "jsons_idx", f"{name}_{dataset}_frameIdx.json")
+
+
+class FrameIdGenerator:
+    """`GEN_Frame_ID_TSPO.generate_inner` (mp_tools/vlmeval/vlm/gen_id_tspo.py:59-92) around a TSPOModel:
+    cache miss -> decode the video (`load_video`, a plug-in: decord is outside this package), `extract_feature`, save the
+    .pth cache; cache hit -> load it, move to the model's device and dtype; then `temporal_sampling` (bin-max for
+    VideoMME, top-k otherwise, window 12) unless the video has no more than `sample_num` frames; returns the selected
+    absolute frame numbers as floats."""
+
+    def __init__(self, model, clip_processor, save_root: str, sample_num: int = 64,
+                 load_video: Optional[Callable] = None):
+        self.tspo_model, self.clip_processor = model, clip_processor
+        self.save_root, self.sample_num, self.load_video = save_root, sample_num, load_video
+        self.cache_hits = self.cache_misses = 0
+
+    @staticmethod
+    def problem_of(question: str) -> str:
+        assert "\nOptions" in question
+        return question.replace("<image>\n", "").replace("Question: ", "").split("\nOptions")[0]
+
+    def generate_inner(self, message, index=None, dataset=None) -> List[float]:
+        import torch
+        video_path, question = message[0]["value"], message[1]["value"]
+        problem = self.problem_of(question)
+        path = feature_cache_path(self.save_root, dataset, index)
+        model = self.tspo_model
+        if not os.path.exists(path):
+            if self.load_video is None:
+                raise FileNotFoundError(f"{path} is not cached and no load_video plug-in was given")
+            video, _, _, sampled_idx = self.load_video(video_path, max_frames_num=50000, fps=1, force_sample=False)
+            image, text, clip = model.extract_feature(self.clip_processor, video, problem)
+            save_feature_cache(path, image, text, clip, sampled_idx)
+            sampled_idx = torch.as_tensor(sampled_idx)
+            self.cache_misses += 1
+        else:
+            image, text, clip, sampled_idx = load_feature_cache(path, model.device, model.dtype)
+            self.cache_hits += 1
+        return select_frame_ids(model, image, text, clip, sampled_idx, dataset, self.sample_num)
 
 
 def extract_selector_state(state: Dict[str, torch.Tensor], prefix: Optional[str] = None) -> Dict[str, torch.Tensor]:

@@ -54,7 +54,7 @@ class _SelectorFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, img, txt, clip, window, tau, *params):
-        flat = module._flat_params()
+        flat = module._flat_params(training=True)   # (grad mode is off inside Function.forward; this IS the training path)
         scores, attn, ws = ops.selector_forward(flat, img, txt, clip, module.num_heads, window, tau)
         ctx.module, ctx.window, ctx.tau, ctx.ws = module, window, tau, ws
         ctx.save_for_backward(img, txt)
@@ -147,21 +147,58 @@ class MultiModal_Align(nn.Module):
         return all(named[n].data_ptr() == base + 4 * offs[n][0] and named[n].dtype == torch.float32
                    for n, _ in ops.FLAT_LAYOUT)
 
-    def _flat_params(self) -> torch.Tensor:
+    def _flat_params(self, training: bool = False) -> torch.Tensor:
         if self._is_flat():
             return self._flat
-        # parameters were replaced (from_pretrained / .to(dtype) / load_state_dict): build a packed fp32 copy, cached
+        # parameters were replaced (from_pretrained / .to(dtype) / load_state_dict): a packed fp32 copy is built.
+        # While training (grad mode on and a trainable parameter) it is rebuilt on EVERY call: optimizers that write
+        # through `p.data` (DeepSpeed / bf16 master-weight copies, EMA swaps) change neither data_ptr nor _version, so no
+        # cache key can see them; the copy is 14 MB.  For inference the copy is cached, keyed on (data_ptr, _version,
+        # dtype) of every tensor; `invalidate_packed()` drops it after an out-of-band in-place update.
         named = self._named()
+        training = training or (torch.is_grad_enabled() and any(p.requires_grad for p in named.values()))
         key = tuple((named[n].data_ptr(), named[n]._version, named[n].dtype) for n, _ in ops.FLAT_LAYOUT)
-        if key != self._cache_key:
+        if training or key != self._cache_key or self._cache_flat is None:
             dev = next(self.parameters()).device
             offs = ops.flat_offsets(self.dim)
-            flat = torch.empty(offs["__total__"][0], dtype=torch.float32, device=dev)
+            flat = self._cache_flat
+            if flat is None or flat.device != dev:
+                flat = torch.empty(offs["__total__"][0], dtype=torch.float32, device=dev)
             for n, _ in ops.FLAT_LAYOUT:
                 off, _shape = offs[n]
-                flat[off:off + named[n].numel()].copy_(named[n].detach().float().flatten())
+                flat[off:off + named[n].numel()].copy_(named[n].detach().flatten())
             self._cache_key, self._cache_flat = key, flat
         return self._cache_flat
+
+    def invalidate_packed(self) -> None:
+        """Forget the cached packed copy of non-flat parameters (call after writing weights through `p.data`)."""
+        self._cache_key, self._cache_flat = None, None
+
+    def _realias_grads(self) -> None:
+        """Flat mode: every p.grad must be a view of the gradient bucket (`optimizer.zero_grad(set_to_none=True)` or
+        `module.zero_grad()` drop the views; autograd would then allocate fresh grads outside the bucket and the bucket the
+        data-parallel trainer all-reduces would silently go stale)."""
+        if self._flat is None or not self._is_flat():
+            return
+        offs = ops.flat_offsets(self.dim)
+        base = self._flat_grad.data_ptr()
+        for n, p in self._named().items():
+            off, shape = offs[n]
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                view = self._flat_grad[off:off + p.numel()].view(shape)
+                if p.grad is not None:
+                    view.copy_(p.grad)
+                else:
+                    view.zero_()
+                p.grad = view
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Flat mode keeps the gradient views alive: the bucket is zeroed in place whatever `set_to_none` says."""
+        if self._flat is not None and self._is_flat():
+            self._flat_grad.zero_()
+            self._realias_grads()
+            return
+        return super().zero_grad(set_to_none=set_to_none)
 
     # ---- forward --------------------------------------------------------------
     def forward(self, input_emb, text_emb, clip_scores=None, window_size=None, score_tau=0.025):
@@ -183,6 +220,7 @@ class MultiModal_Align(nn.Module):
         """img [B,T,D], txt [B,M,D], clip [B,T] -> (scores f32 [B,T], temporal_attn f32 [B,T,D])."""
         params = [p for _, p in self._trainable_named()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            self._realias_grads()
             return _SelectorFn.apply(self, img, txt, clip, int(window_size), float(score_tau), *params)
         scores, attn, _ = ops.selector_forward(self._flat_params(), img, txt, clip, self.num_heads, int(window_size),
                                                float(score_tau))
@@ -190,10 +228,13 @@ class MultiModal_Align(nn.Module):
 
 
 def _image_features(clip_model, pixel_values):
-    """HIP CLIP-L encode with weights packed (once) from the HF module's state."""
+    """HIP CLIP-L encode with weights packed from the HF module's state.  The packed bf16 copy is cached on the module,
+    keyed on (data_ptr, _version) of EVERY vision-tower tensor and the device: load_state_dict / an in-place update /
+    .to(device) rebuild it.  (Writes through `p.data` are invisible to any key: call `invalidate_packed_clip(model)`.)"""
     packed = getattr(clip_model, "_tspo_packed", None)
     vm = clip_model.vision_model
-    key = (next(vm.parameters()).data_ptr(), next(vm.parameters()).device)
+    tensors = list(vm.parameters()) + [clip_model.visual_projection.weight]
+    key = (tensors[0].device, tuple((t.data_ptr(), t._version) for t in tensors))
     if packed is None or packed[0] != key:
         cfg = clip_model.config.vision_config
         c = dict(hidden=cfg.hidden_size, layers=cfg.num_hidden_layers, heads=cfg.num_attention_heads,
@@ -201,9 +242,18 @@ def _image_features(clip_model, pixel_values):
                  proj=clip_model.config.projection_dim, ln_eps=cfg.layer_norm_eps)
         state = {"vision_model." + k: v for k, v in vm.state_dict().items()}
         state["visual_projection.weight"] = clip_model.visual_projection.weight
-        packed = (key, ops.ClipVitWeights(state, c, key[1]))
+        packed = (key, ops.ClipVitWeights(state, c, key[0]))
         clip_model._tspo_packed = packed
     return ops.clip_vit_forward(packed[1], pixel_values)
+
+
+def invalidate_packed_clip(clip_model) -> None:
+    clip_model._tspo_packed = None
+
+
+def _flash_attn_available() -> bool:
+    import importlib.util
+    return importlib.util.find_spec("flash_attn") is not None
 
 
 def _pooled(out):
@@ -312,6 +362,17 @@ class TSPOModel(CLIPModel):
 
     def save_pretrained(self, save_directory: str, **kwargs):
         super().save_pretrained(save_directory, **kwargs)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, **kwargs):
+        """HF entry point exactly as the reference's callers use it (mp_tools/vlmeval/vlm/gen_id_tspo.py:55:
+        `from_pretrained(path, attn_implementation="flash_attention_2", torch_dtype=torch.bfloat16, device_map="auto")`).
+        `flash_attention_2` only ever applied to the two stock CLIP towers; here the vision tower's attention is the HIP
+        kernel whatever this says, and the <= 77-token text tower runs on stock PyTorch-ROCm: when the flash_attn
+        package is not installed (it is not part of the ROCm image) the request maps to PyTorch SDPA instead of raising."""
+        if kwargs.get("attn_implementation") == "flash_attention_2" and not _flash_attn_available():
+            kwargs["attn_implementation"] = "sdpa"
+        return super().from_pretrained(pretrained_model_name_or_path, *model_args, **kwargs)
 
 
 def inference_ts(confidence, method, sample_len):

@@ -1,0 +1,237 @@
+"""TSPO policy training driver on MI355X - what `train_deepspeed.sh` + `src/open_tspo/tspo.py` +
+`LLaVAVideoTSPOTrainer` do for the temporal agent, without DeepSpeed / TRL:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        -m tspo_amd.train --features /data/tspo_feats --output-dir ckpt/tspo --max-steps 1000
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Only the 2.95 M selector parameters train,
+so the whole exchange is ONE all-reduce of the flat fp32 gradient bucket per optimizer step (`PolicyTrainer`) plus one
+packed metrics all-reduce; ZeRO-3 (scripts/zero3.json) has nothing to shard here.
+
+Reference behaviour kept (file:line of the reference):
+  * per_device_train_batch_size 1, gradient_accumulation_steps 2, lr 5e-4 with the HF Trainer's default linear decay,
+    num_generations 8, window_size 12, training_sample_len 16, score_tau 0.025, save_steps 100, save_total_limit 8,
+    save_only_model (train_deepspeed.sh:14-42)
+  * temperature annealing tau(step) (tspo_trainer.py:496), sample_len halved for "general" items (:510-513)
+  * rewards per function, 'specific' = sum / 'general' = accuracy + 1 (:554-573), group-relative advantage (:587-592)
+  * metrics averaged over ranks and logged every step (:610-650) - here as JSON lines
+  * checkpoints hold the selector under the training prefix `multiModal_align.` (scripts/merge_weights.py:19-24 reads it)
+The frozen video-LLM that turns the selected frames into an answer is a plug-in (`reward_model`, stock PyTorch-ROCm);
+without one the driver uses the temporal-localisation reward on needle-in-a-haystack masks plus a mask-overlap proxy for
+the accuracy reward, which exercises the complete policy path.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import time
+from dataclasses import asdict, dataclass
+from typing import Callable, Dict, Iterator, List, Optional
+
+import torch
+
+from . import dist as tdist
+from . import io as tio
+from . import ops, rewards
+from .pipeline import PolicyTrainer, annealed_tau, linear_decay_lr
+
+
+@dataclass
+class TrainConfig:
+    output_dir: str = "ckpt/tspo"
+    max_steps: int = 100
+    num_generations: int = 8
+    window_size: int = 12
+    training_sample_len: int = 16
+    score_tau: float = 0.025
+    learning_rate: float = 5e-4
+    gradient_accumulation_steps: int = 2
+    per_device_train_batch_size: int = 1
+    max_grad_norm: float = 1.0
+    save_steps: int = 100
+    save_total_limit: int = 8
+    logging_steps: int = 1
+    seed: int = 42
+    dim: int = 768
+    heads: int = 8
+    gemm_precision: str = "fp32"
+
+
+class Batch:
+    """One micro-batch of prompts on this rank: features [B,T,D], text [B,1,D], clip [B,T], mask [B,T] bool, type."""
+
+    def __init__(self, feats, txt, clip, mask, item_type="specific", meta=None):
+        self.feats, self.txt, self.clip, self.mask, self.item_type, self.meta = feats, txt, clip, mask, item_type, meta
+
+
+class SyntheticFeatures:
+    """Seeded stand-in for the feature cache: unit-normal frame features in which the frames of a planted segment are
+    pulled towards the text feature, so the clip score and the relevance mask carry signal."""
+
+    def __init__(self, T=512, D=768, seed=0, device="cuda"):
+        self.T, self.D, self.seed, self.dev = T, D, seed, torch.device(device)
+
+    def batches(self, rank: int, world: int, bs: int) -> Iterator[Batch]:
+        i = 0
+        while True:
+            g = torch.Generator(device=self.dev).manual_seed(self.seed * 1_000_003 + (i * world + rank))
+            f = torch.randn(bs, self.T, self.D, generator=g, device=self.dev)
+            t = torch.randn(bs, 1, self.D, generator=g, device=self.dev)
+            start = torch.randint(0, self.T - self.T // 8, (bs,), generator=g, device=self.dev)
+            pos = torch.arange(self.T, device=self.dev)[None]
+            mask = (pos >= start[:, None]) & (pos < start[:, None] + self.T // 8)
+            f = f + 0.75 * mask[..., None] * t
+            yield Batch(f, t, ops.clip_scores(t, f), mask, "specific" if i % 4 else "general")
+            i += 1
+
+
+class FeatureCacheDataset:
+    """Feature-cache files of the evaluation / training flow (tspo_amd.io: {"image","text","clip_scores","sampled_idx"},
+    optional "mask" [T] bool and "type")."""
+
+    def __init__(self, root: str, device="cuda"):
+        self.files = sorted(glob.glob(os.path.join(root, "**", "*.pth"), recursive=True))
+        if not self.files:
+            raise FileNotFoundError(f"no *.pth feature caches under {root}")
+        self.dev = torch.device(device)
+
+    def batches(self, rank: int, world: int, bs: int) -> Iterator[Batch]:
+        assert bs == 1, "videos differ in length: one prompt per micro-batch, like the reference (per_device_train_batch_size 1)"
+        mine = [self.files[i] for i in tdist.shard_prompts(len(self.files), world, rank)] or self.files
+        while True:
+            for path in mine:
+                stat = torch.load(path, map_location="cpu")
+                img = stat["image"].to(self.dev).float()[None]
+                txt = stat["text"].to(self.dev).float().reshape(1, -1, img.shape[-1])[:, :1]
+                clip = stat["clip_scores"].to(self.dev).float().reshape(1, -1)
+                mask = stat.get("mask", torch.ones(img.shape[1], dtype=torch.bool)).to(self.dev).reshape(1, -1)
+                yield Batch(img, txt, clip, mask, stat.get("type", "specific"), {"path": path})
+
+
+def mask_reward_model(idx: torch.Tensor, batch: Batch) -> torch.Tensor:
+    """Default reward plug-in -> rewards_per_func [B, G, 2] = (accuracy proxy, temporal localisation).  The temporal
+    column is the reference's reward (tspo.py:146-159); the accuracy column stands in for the frozen video-LLM's answer
+    check: 1 when at least 40 % of the selected frames are relevant (the iou gate left commented at tspo.py:131-134)."""
+    temporal = rewards.selection_mask_reward_gpu(idx, batch.mask)
+    return torch.stack([(temporal > 0.4).float(), temporal], dim=-1)
+
+
+REWARD_NAMES = ("accuracy_reward", "temporal_localization_reward")
+
+
+def _ckpt_dirs(out: str) -> List[str]:
+    ds = [d for d in glob.glob(os.path.join(out, "checkpoint-*")) if os.path.isdir(d)]
+    return sorted(ds, key=lambda d: int(d.rsplit("-", 1)[1]))
+
+
+def save_checkpoint(trainer: PolicyTrainer, cfg: TrainConfig, step: int) -> str:
+    d = os.path.join(cfg.output_dir, f"checkpoint-{step}")
+    os.makedirs(d, exist_ok=True)
+    offs = ops.flat_offsets(trainer.dim)
+    import math
+    state = {k: trainer.flat[o:o + math.prod(s)].view(s).clone() for k, (o, s) in offs.items() if not k.startswith("__")}
+    tio.save_selector_safetensors(state, os.path.join(d, "model.safetensors"), prefix=tio.TRAIN_PREFIX)
+    torch.save(trainer.state_dict(), os.path.join(d, "optimizer.pt"))       # (save_only_model in the reference; kept for resume)
+    with open(os.path.join(d, "trainer_state.json"), "w") as f:
+        json.dump({"global_step": step, "config": asdict(cfg)}, f)
+    for old in _ckpt_dirs(cfg.output_dir)[:-cfg.save_total_limit]:
+        for p in glob.glob(os.path.join(old, "*")):
+            os.remove(p)
+        os.rmdir(old)
+    return d
+
+
+def train(cfg: TrainConfig, data, reward_model: Callable[[torch.Tensor, Batch], torch.Tensor] = mask_reward_model,
+          flat: Optional[torch.Tensor] = None, backend: str = "nccl", resume: bool = True,
+          log: Optional[Callable[[Dict], None]] = None, stop_after: Optional[int] = None) -> Dict:
+    """Runs cfg.max_steps optimizer steps on this rank's shard (resuming from the newest checkpoint in cfg.output_dir);
+    returns the last logged metrics.  `stop_after` ends the run early after that global step, with a checkpoint (tests)."""
+    rank, world, local = tdist.init_from_env(backend)
+    dev = torch.device("cuda", local if torch.cuda.device_count() > local else 0)
+    torch.cuda.set_device(dev)
+    if flat is None:
+        g = torch.Generator(device=dev).manual_seed(cfg.seed)            # HF _init_weights: N(0, 0.02), zero bias
+        offs = ops.flat_offsets(cfg.dim)
+        flat = torch.zeros(offs["__total__"][0], dtype=torch.float32, device=dev)
+        for k, (o, s) in offs.items():
+            if k.endswith(".weight"):
+                flat[o:o + cfg.dim * cfg.dim] = torch.randn(cfg.dim * cfg.dim, generator=g, device=dev) * 0.02
+    trainer = PolicyTrainer(flat, dim=cfg.dim, heads=cfg.heads, window_size=cfg.window_size, lr=cfg.learning_rate,
+                            max_grad_norm=cfg.max_grad_norm, seed=cfg.seed, grad_accum_steps=cfg.gradient_accumulation_steps,
+                            lr_schedule=linear_decay_lr(cfg.learning_rate, cfg.max_steps), gemm_precision=cfg.gemm_precision)
+    start = 0
+    if resume and _ckpt_dirs(cfg.output_dir):
+        last = _ckpt_dirs(cfg.output_dir)[-1]
+        trainer.load_state_dict(torch.load(os.path.join(last, "optimizer.pt"), map_location=dev))
+        start = int(json.load(open(os.path.join(last, "trainer_state.json")))["global_step"])
+    os.makedirs(cfg.output_dir, exist_ok=True)
+    logf = open(os.path.join(cfg.output_dir, "metrics.jsonl"), "a") if rank == 0 else None
+    it = data.batches(rank, world, cfg.per_device_train_batch_size)
+    for _ in range(start * cfg.gradient_accumulation_steps):                   # deterministic data order across resumes
+        next(it)
+    last_metrics: Dict = {}
+    t0 = time.perf_counter()
+    for step in range(start, cfg.max_steps):
+        tau = annealed_tau(cfg.score_tau, step, cfg.max_steps)
+        acc_m: Dict[str, float] = {k: 0.0 for k in tdist.METRIC_KEYS}
+        acc_r = [0.0] * len(REWARD_NAMES)
+        loss_v = 0.0
+        for _micro in range(cfg.gradient_accumulation_steps):
+            b = next(it)
+            k = rewards.training_sample_len(cfg.training_sample_len, b.item_type)
+            scores, idx, logp, ctx = trainer.rollout(b.feats, b.txt, b.clip, cfg.num_generations, k, tau)
+            rpf = reward_model(idx, b)                                           # [B, G, F]   (frozen video-LLM plug-in)
+            B, G, F = rpf.shape
+            rew = rewards.combine_rewards(rpf.reshape(B * G, F), b.item_type).reshape(B, G)
+            st = trainer.backward(ctx, b.feats, b.txt, logp, idx, rew)
+            w = 1.0 / cfg.gradient_accumulation_steps
+            acc_m["ts_length"] += w * k
+            acc_m["reward"] += w * rew.mean().item()
+            acc_m["advantages"] += w * st["advantages"].mean().item()
+            acc_m["reward_mean"] += w * rew.mean(dim=1).mean().item()
+            acc_m["reward_std"] += w * rew.std(dim=1).mean().item()
+            for j in range(len(REWARD_NAMES)):
+                acc_r[j] += w * rpf[..., j].mean().item()
+            loss_v += w * st["loss"].mean().item()
+        ost = trainer.optimizer_step()
+        if (step + 1) % cfg.logging_steps == 0:
+            m = tdist.reduce_metrics(tdist.pack_metrics(acc_m, acc_r), len(REWARD_NAMES), REWARD_NAMES)
+            m.update(step=step + 1, loss=loss_v, learning_rate=ost["lr"], score_tau=tau,
+                     grad_norm=float(ost["grad_norm_scale"][0]) / ost["world"], elapsed_s=round(time.perf_counter() - t0, 3))
+            last_metrics = m
+            if logf:
+                logf.write(json.dumps(m) + "\n")
+                logf.flush()
+            if log:
+                log(m)
+        stop = stop_after is not None and step + 1 >= stop_after
+        if rank == 0 and ((step + 1) % cfg.save_steps == 0 or step + 1 == cfg.max_steps or stop):
+            save_checkpoint(trainer, cfg, step + 1)
+        if stop:
+            break
+    if logf:
+        logf.close()
+    last_metrics["flat"] = trainer.flat
+    return last_metrics
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--features", default=None, help="directory of feature-cache .pth files (default: synthetic features)")
+    ap.add_argument("--frames", type=int, default=512, help="T of the synthetic features")
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--no-resume", action="store_true")
+    for name, val in asdict(TrainConfig()).items():
+        ap.add_argument("--" + name.replace("_", "-"), type=type(val), default=val)
+    a = ap.parse_args(argv)
+    cfg = TrainConfig(**{k: getattr(a, k) for k in asdict(TrainConfig())})
+    data = FeatureCacheDataset(a.features) if a.features else SyntheticFeatures(T=a.frames, D=cfg.dim, seed=cfg.seed)
+    m = train(cfg, data, backend=a.backend, resume=not a.no_resume,
+              log=lambda r: print(json.dumps(r), flush=True) if int(os.environ.get("RANK", "0")) == 0 else None)
+    return 0 if m else 1
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
