@@ -190,14 +190,12 @@ def main():
 
     from tspo_amd import ops
     from tspo_amd.pipeline import FrameScorer, PolicyTrainer
-    if a.no_ln_fold:
-        ops.FOLD_LAYERNORM = False
 
     c = CLIP_L14
     B, T, k = a.videos, a.frames, a.topk
     clipw = ops.ClipVitWeights(random_clip_state(c, dev), c, dev)
     flat = flat_from_state(random_selector_state(768, dev), 768, dev)
-    scorer = FrameScorer(clipw, flat)
+    scorer = FrameScorer(clipw, flat, fold_layernorm=not a.no_ln_fold)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     if a.pixels == "u8":
         pixels = torch.randint(0, 256, (B, T, 3, c["image"], c["image"]), generator=g, device=dev, dtype=torch.uint8)
@@ -241,9 +239,9 @@ def main():
     # because `value` must execute the full model like the reference does)
     pruned_fps = None
     if not a.no_pruned:
-        ops.PRUNE_LAST_LAYER = True
+        scorer.prune_last_layer = True
         psec = timed(score_step, a.steps, 1)
-        ops.PRUNE_LAST_LAYER = False
+        scorer.prune_last_layer = False
         pruned_fps = frames / psec
         assert bool((out["idx"][:, 1:] > out["idx"][:, :-1]).all())
         score_step()   # restore the full-model outputs used by the checks below
@@ -280,14 +278,14 @@ def main():
     roof = None
     if rank == 0 and not a.no_profile:
         px = pixels.reshape(B * T, *pixels.shape[2:])
-        ops.clip_vit_profile(clipw, px)
-        pr = ops.clip_vit_profile(clipw, px)
+        ops.clip_vit_profile(clipw, px, fold_layernorm=not a.no_ln_fold)
+        pr = ops.clip_vit_profile(clipw, px, fold_layernorm=not a.no_ln_fold)
         gflop = gemm_flops_per_frame(c) * B * T
         ach = gflop / (pr["gemm_ms"] * 1e-3) / 1e12
         # HBM-side bytes per GEMM launch: cannot be read from inside the process; taken from the committed PMC passes
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, tools/pmc_traffic.py) when they match this config
         traffic, tsrc = None, None
-        tname = "r1_e_gemm_hbm_traffic_T1024.json" if ops.FOLD_LAYERNORM else "r1_gemm_hbm_traffic_T1024.json"
+        tname = "r1_e_gemm_hbm_traffic_T1024.json" if not a.no_ln_fold else "r1_gemm_hbm_traffic_T1024.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and B * T == 1024:
             try:

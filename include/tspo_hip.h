@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TSPO_ABI_VERSION 1
+#define TSPO_ABI_VERSION 2
 
 enum tspo_error {
   TSPO_OK = 0,
@@ -229,18 +229,28 @@ size_t tspo_clip_workspace_bytes(const tspo_clip_config* cfg, int n_frames);
  * the patch gather.  bf16 MFMA GEMMs with fp32 accumulation, bf16 activations.
  * feat f32 [N, proj].  For batches of >= 64 frames the per-layer LayerNorms
  * are folded into the GEMMs around them (same maths, statistics taken from
- * the bf16 residual stream as stored); OR-ing 0x100 into pixel_dtype keeps
- * the stand-alone LayerNorm passes (A/B test hook).                         */
+ * the bf16 residual stream as stored).                                       */
 int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
                           float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream);
+
+/* tspo_clip_vit_forward with option flags (0 = exactly tspo_clip_vit_forward):
+ *   TSPO_CLIP_NO_LN_FOLD  keep the stand-alone LayerNorm passes on large batches too (A/B comparison);
+ *   TSPO_CLIP_PRUNE_LAST  evaluate the LAST transformer block for the class-token row only - get_image_features
+ *                         pools token 0, the other 256 token rows of that block have no consumer; same features up
+ *                         to the different GEMM kernel of the small [n_frames, C] matrices (opt-in, off by default:
+ *                         the default executes the full model like the reference).                            */
+#define TSPO_CLIP_NO_LN_FOLD 1
+#define TSPO_CLIP_PRUNE_LAST 2
+int tspo_clip_vit_forward_ex(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
+                             float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags);
 
 /* Same computation, with a hipEvent recorded on `stream` after every kernel launch; synchronises on the
  * last event (profiling entry point - the only one that waits) and returns in HOST array host_ms6:
  * [0] GEMM ms, [1] attention ms, [2] LayerNorm ms, [3] patch gather ms, [4] total ms, [5] number of GEMM
- * launches.  bench.py derives roofline.achieved for the GEMM kernel from [0].                              */
+ * launches.  bench.py derives roofline.achieved for the GEMM kernel from [0].  flags as for _ex.              */
 int tspo_clip_vit_profile(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
                           float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
-                          float* host_ms6);
+                          float* host_ms6, int flags);
 
 /* On-device CLIPImageProcessor front half: uint8 frames [T,H,W,3] (layout 0) or [T,3,H,W] (layout 1) ->
  * Pillow-exact antialiased bicubic resize + centre crop -> uint8 [T,3,out_h,out_w].  Replaces the per-frame
@@ -264,8 +274,10 @@ int tspo_clip_scores(const float* txt, const float* feat, int B, int T, int D, i
 /* Generic bf16 MFMA GEMM exposed for tests / micro-benchmarks:
  * C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, f32 accumulate, out bf16 or f32.
  * K % 64 == 0.  act (bits 0-7): 0 none, 1 quick_gelu.  residual (bf16 [M,N], nullable) is added.
- * Bits 8+ of `act` select a kernel variant for A/B tests and ablations (tools/bench_gemm.py; some ablation
- * variants deliberately compute wrong results) - production callers pass 0 there.                          */
+ * Bits 8+ of `act` choose the kernel: 0 = automatic (what the encoder uses), 1 = small-problem 128x128 kernel,
+ * 6 = 8-wave LDS-DMA ring kernel, 82 = 4-wave AGPR kernel (K % 128 == 0).  Every choice computes the same result
+ * (bit-identical between 6 and 82); other values exist only in a -DTSPO_DEV_HOOKS build (A/B variants, ablations)
+ * and are rejected with TSPO_EINVAL by the shipped library.                                                   */
 int tspo_gemm_bf16(const void* A, const void* W, const float* bias, const void* residual,
                    void* C, int out_dtype, int M, int N, int K, int act, tspo_stream_t stream);
 

@@ -23,7 +23,7 @@ def test_build_and_symbols():
     for s in hs:
         assert hasattr(l, s), f"{s} declared in tspo_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == hs, "ctypes binding and header disagree"
-    assert l.tspo_version() == 1
+    assert l.tspo_version() == 2 == _lib.ABI_VERSION
 
 
 def test_argument_validation_without_gpu():
@@ -58,3 +58,54 @@ def test_product_has_no_cpu_fallback():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_shipped_library_has_no_dev_hooks():
+    """The GEMM A/B variants / ablation kernels exist only in a -DTSPO_DEV_HOOKS build: the shipped library rejects
+    their variant numbers before touching the device and does not contain their kernels."""
+    from tspo_amd import _lib
+    l = _lib.lib()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    for variant in (2, 8, 9, 60, 69, 70, 71):        # 256x128 ring, compute-only / loads-only ablations, probe, role-split, 16-wave
+        assert l.tspo_gemm_bf16(p, p, p, None, p, _lib.TSPO_BF16, 4096, 4096, 1024, variant << 8, None) == -1
+        assert b"not part of this build" in l.tspo_last_error()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"gemm_bf16_p3_kernel", b"gemm_bf16_s256_kernel", b"gemm_bf16_w16_kernel"):
+        assert name not in blob, name
+    assert b"gemm_bf16_a7_kernel" in blob and b"gemm_bf16_p256_kernel" in blob
+
+
+def test_agpr_gemm_code_audit(tmp_path):
+    """gemm_agpr.hip keeps 256 accumulators per lane in AGPRs under literal names that the compiler does not know about.
+    That is only sound if hipcc itself never touches an AGPR in that kernel and does not spill inside the MFMA loop:
+    audit the generated gfx950 code of every instantiation (device-only -S compile, ~1 min)."""
+    import subprocess
+    from tspo_amd import build as b
+    asm = tmp_path / "gemm_agpr.s"
+    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                           os.path.join(b.CSRC, "gemm_agpr.hip"), "-o", str(asm)])
+    txt = open(asm).read()
+    kernels = re.findall(r"^(_ZN\S*gemm_bf16_a7_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end", txt, flags=re.S | re.M)
+    assert len(kernels) == 8, [k[0] for k in kernels]
+    for name, body in kernels:
+        inasm, bad = False, []
+        blocks, cur = [], []
+        for ln in body.split("\n"):
+            t = ln.strip()
+            if re.match(r"^\.LBB\d+_\d+:", t):
+                blocks.append(cur)
+                cur = []
+            if t.startswith(";;#ASMSTART"):
+                inasm = True
+            elif t.startswith(";;#ASMEND"):
+                inasm = False
+            elif not inasm and t and not t.startswith((";", ".")) and (re.search(r"\ba\[?\d+", t) or "accvgpr" in t):
+                bad.append(t)
+            cur.append(t)
+        blocks.append(cur)
+        assert not bad, f"{name}: compiler-emitted AGPR access outside the asm statements: {bad[:3]}"
+        for blk in blocks:
+            if sum(x.startswith("v_mfma") for x in blk) >= 32:       # the K-loop bodies
+                assert not any(x.startswith("scratch_") for x in blk), f"{name}: scratch access inside an MFMA block"
+        assert body.count("v_mfma_f32_16x16x32_bf16") >= 6 * 64

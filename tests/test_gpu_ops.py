@@ -74,6 +74,17 @@ def _check_logp(got, ref):
     assert np.all(got[~normal] < -86.0)
 
 
+def test_topk_sorted_long_video_beyond_lds():
+    """The evaluation harness samples up to 50000 frames at 1 fps (gen_id_tspo.py:70): rows longer than the 16384 keys that
+    fit in LDS take the global-key path of the radix select; same indices as the oracle, ties -> lowest index."""
+    for T, k in [(16385, 64), (50000, 64), (50000, 1), (20000, 20000)]:
+        s = T_(synth.normal((2, T), 31 + T))
+        s[1, ::7] = s[1, 3]                      # many exact ties
+        got = ops.topk_sorted(s.to(DEV), k).cpu()
+        for b in range(2):
+            assert got[b].tolist() == O.topk_sorted(s[b], k).tolist(), (T, k, b)
+
+
 @pytest.mark.parametrize("case", GUMBEL_CASES, ids=[c[0] for c in GUMBEL_CASES])
 def test_gumbel_topk_injected_noise(golden, case):
     name, T, k, G, scale = case
@@ -428,7 +439,7 @@ def test_gemm_bf16_persistent_kernel_full_check(N, K):
         want, kw = ref + R.float(), dict(residual=R.to(DEV))
     else:
         want, kw = ref, {}
-    for variant in (0, 6, 82, 2, 70, 71):     # auto, 8-wave LDS-DMA ring, 4-wave AGPR register-staged, 256x128 ring, role-split, 16-wave
+    for variant in (0, 6, 82):     # automatic choice, 8-wave LDS-DMA ring kernel, 4-wave AGPR register-staged kernel
         act = kw.get("act", 0) | (variant << 8)
         out = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=act).float().cpu()
         np.testing.assert_allclose(out.numpy(), want.numpy(), err_msg=f"variant {variant}", **tol)

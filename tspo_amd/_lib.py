@@ -12,6 +12,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libtspo_hip.so")
 
 TSPO_F32, TSPO_BF16, TSPO_F16, TSPO_U8 = 0, 1, 2, 3
+TSPO_CLIP_NO_LN_FOLD, TSPO_CLIP_PRUNE_LAST = 1, 2
+ABI_VERSION = 2
 
 _p = C.c_void_p
 _i = C.c_int
@@ -62,7 +64,8 @@ SIGNATURES = {
     "tspo_adamw_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _p, _p]),
     "tspo_clip_workspace_bytes": (_sz, [C.POINTER(ClipConfig), _i]),
     "tspo_clip_vit_forward": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p]),
-    "tspo_clip_vit_profile": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p, C.POINTER(C.c_float)]),
+    "tspo_clip_vit_forward_ex": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p, _i]),
+    "tspo_clip_vit_profile": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p, C.POINTER(C.c_float), _i]),
     "tspo_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
     "tspo_preprocess_frames": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "tspo_clip_scores": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
@@ -91,8 +94,8 @@ def lib():
         fn = getattr(l, name)
         fn.restype = res
         fn.argtypes = args
-    if l.tspo_version() != 1:
-        raise TspoHipError(f"ABI version mismatch: library {l.tspo_version()} != binding 1")
+    if l.tspo_version() != ABI_VERSION:
+        raise TspoHipError(f"ABI version mismatch: library {l.tspo_version()} != binding {ABI_VERSION}")
     _lib = l
     return l
 

@@ -29,15 +29,17 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+    """dev=True adds -DTSPO_DEV_HOOKS: the GEMM A/B variants, ablation branches and timing probes the tools/ scripts use
+    (some compute wrong results on purpose).  The shipped library is built WITHOUT it."""
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
     objs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+              (["-DTSPO_DEV_HOOKS"] if dev else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -50,5 +52,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv or "--dev" in sys.argv, dev="--dev" in sys.argv)
     print(LIB)

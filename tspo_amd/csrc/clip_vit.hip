@@ -627,27 +627,33 @@ extern "C" int tspo_gemm_bf16(const void* A, const void* W, const float* bias, c
   } else {
     TSPO_REQUIRE(out_dtype == TSPO_BF16, "gemm_bf16: out_dtype must be TSPO_BF16 or TSPO_F32");
     TSPO_REQUIRE(bias, "gemm_bf16: bf16 output needs a bias vector");
+#ifdef TSPO_DEV_HOOKS
     TSPO_REQUIRE(!(residual && act) || variant == 69, "gemm_bf16: residual and activation are exclusive");
+#else
+    TSPO_REQUIRE(!(residual && act), "gemm_bf16: residual and activation are exclusive");
+#endif
     epi = residual ? GE_RESID : (act == 1 ? GE_GELU : GE_BIAS);
   }
   g.variant = variant;
+#ifdef TSPO_DEV_HOOKS
   if (variant == 69) {   // timing probe: the `residual` argument is a float debug buffer [256*8*4], not a residual
     g.pos = reinterpret_cast<const float*>(residual);
     g.R = nullptr;
     epi = act == 1 ? GE_GELU : GE_BIAS;
   }
+#endif
   return tspo::gemm_bf16(epi, g, (hipStream_t)stream);
 }
 
 static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames, float* feat,
-                             void* workspace, size_t workspace_bytes, tspo_stream_t stream, Prof& prof) {
+                             void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags, Prof& prof) {
   TSPO_REQUIRE(w && pixels && feat && workspace, "clip_vit_forward: null pointer");
   TSPO_REQUIRE(n_frames >= 1, "clip_vit_forward: n_frames=%d", n_frames);
   const tspo_clip_config& c = w->cfg;
   if (int e = clip_check_cfg(c)) return e;
-  const bool no_fold = (pixel_dtype & 0x100) != 0;   // test hook: keep the stand-alone LayerNorm passes
-  const bool prune = (pixel_dtype & 0x200) != 0;     // opt-in: last block evaluated for the class-token row only
-  pixel_dtype &= 0xff;
+  TSPO_REQUIRE((flags & ~(TSPO_CLIP_NO_LN_FOLD | TSPO_CLIP_PRUNE_LAST)) == 0, "clip_vit_forward: unknown flags 0x%x", flags);
+  const bool no_fold = (flags & TSPO_CLIP_NO_LN_FOLD) != 0;   // keep the stand-alone LayerNorm passes
+  const bool prune = (flags & TSPO_CLIP_PRUNE_LAST) != 0;     // opt-in: last block evaluated for the class-token row only
   TSPO_REQUIRE(w->patch_w && w->pos_emb && w->pre_g && w->pre_b && w->post_g && w->post_b && w->proj_w &&
                    (c.layers == 0 || w->layers),
                "clip_vit_forward: null weight pointer");
@@ -799,19 +805,25 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
   return TSPO_OK;
 }
 
+extern "C" int tspo_clip_vit_forward_ex(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
+                                        float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
+                                        int flags) {
+  Prof prof;
+  return clip_forward_impl(w, pixels, pixel_dtype, n_frames, feat, workspace, workspace_bytes, stream, flags, prof);
+}
+
 extern "C" int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
                                      float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream) {
-  Prof prof;
-  return clip_forward_impl(w, pixels, pixel_dtype, n_frames, feat, workspace, workspace_bytes, stream, prof);
+  return tspo_clip_vit_forward_ex(w, pixels, pixel_dtype, n_frames, feat, workspace, workspace_bytes, stream, 0);
 }
 
 extern "C" int tspo_clip_vit_profile(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
                                      float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
-                                     float* host_ms6) {
+                                     float* host_ms6, int flags) {
   TSPO_REQUIRE(host_ms6, "clip_vit_profile: null host_ms6");
   static thread_local Prof prof;  // 512 events: keep it off the stack
   prof.start((hipStream_t)stream);
-  const int rc = clip_forward_impl(w, pixels, pixel_dtype, n_frames, feat, workspace, workspace_bytes, stream, prof);
+  const int rc = clip_forward_impl(w, pixels, pixel_dtype, n_frames, feat, workspace, workspace_bytes, stream, flags, prof);
   prof.finish(host_ms6);
   prof.on = false;
   return rc;

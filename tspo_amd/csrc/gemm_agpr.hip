@@ -70,13 +70,13 @@ __device__ __forceinline__ float a4_acc_read() {
   return x;
 }
 
-// What a 64-column slice of the wave's tile needs from memory besides the residual: bias / folded bias, LayerNorm column
-// sums, (rstd, -mean*rstd) of the lane's 8 rows.  Slice 0's copy is fetched one K-step BEFORE the epilogue (behind the
-// MFMAs of the tile's last K-step), slice 1's at the start of the epilogue - so no load latency is exposed for them.
-struct EpiPre { EpiCols ec; float2 rst[8]; };
+// What a 64-column slice of the wave's tile needs from memory besides the residual: bias / folded bias and LayerNorm
+// column sums.  Slice 0's copy is requested one K-step BEFORE the epilogue (behind the MFMAs of the tile's last K-step),
+// slice 1's at the start of the epilogue - no load latency is exposed for them.  The (rstd, -mean*rstd) pairs of the
+// lane's 8 rows are the same for both slices and are requested first thing in the epilogue.
+struct EpiPre { EpiCols ec; };
 template <int EPI>
-__device__ __forceinline__ void epi_prefetch(const GemmArgs& g, int m0, int n0, int wm, int ws, int l15, int q4, EpiPre& p) {
-  constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
+__device__ __forceinline__ void epi_prefetch(const GemmArgs& g, int n0, int ws, int q4, EpiPre& p) {
   g3_epi_cols<EPI>(g, n0, ws, q4, p.ec);
   if (epi_has_bias(EPI)) {
 #pragma unroll
@@ -85,8 +85,6 @@ __device__ __forceinline__ void epi_prefetch(const GemmArgs& g, int m0, int n0, 
       p.ec.bias[ni] = *reinterpret_cast<const f32x4*>(g.bias + (n < g.N ? n : 0));
     }
   }
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) p.rst[mi] = LN ? g3_epi_rowstat(g, m0 + wm * 128 + mi * 16 + l15) : make_float2(1.f, 0.f);
 }
 
 // Epilogue of the wave's 128x128 tile held in a[0:255].  The residual tile comes in 16-byte loads in the STORE mapping
@@ -99,8 +97,12 @@ __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0,
                                               const EpiPre& p0) {
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first v_accvgpr_read
   constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
+  constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
+  float2 rst[8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) rst[mi] = LN ? g3_epi_rowstat(g, m0 + wm * 128 + mi * 16 + l15) : make_float2(1.f, 0.f);
   EpiPre p1;
-  epi_prefetch<EPI>(g, m0, n0, wm, wn * 2 + 1, l15, q4, p1);
+  epi_prefetch<EPI>(g, n0, wn * 2 + 1, q4, p1);
   uint4 rres[8][2];
   auto rload = [&](int mi, int ws) {
     const int m = m0 + wm * 128 + mi * 16 + l15;
@@ -140,7 +142,7 @@ __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0,
         }
         if (nhs == 0) rload(mi, wn * 2 + 1);
       }
-      g3_epi_row<EPI, true, FULL>(g, vv, p.ec, p.rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
+      g3_epi_row<EPI, true, FULL>(g, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
     });
   });
 }
@@ -296,9 +298,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
       kstep(std::false_type{}, sa0);
     }
     EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
-    if (PRE0) epi_prefetch<EPI>(g, m0, n0, wm, wn * 2, l15, q4, p0);
+    if (PRE0) epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
     kstep(std::false_type{}, A2 ? sa1 : sa0);
-    if (!PRE0) epi_prefetch<EPI>(g, m0, n0, wm, wn * 2, l15, q4, p0);
+    if (!PRE0) epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
     if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
     else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
     c_s += nwl;
@@ -328,7 +330,9 @@ template <int EPI>
 int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
   if ((g.K / GT_BK) % 2 != 0 || g.K < 2 * GT_BK)
     return tspo::set_err(TSPO_EINVAL, "gemm_agpr: K=%d must be a multiple of 128", g.K);
+#ifdef TSPO_DEV_HOOKS
   if (g.variant == 83) return launch_gemm_a7<EPI, true, false>(g, st);    // A/B: A two K-steps ahead, no early epilogue prefetch
+#endif
   return launch_gemm_a7<EPI, false, true>(g, st);
 }
 }  // namespace

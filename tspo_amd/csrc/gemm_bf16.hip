@@ -4,6 +4,17 @@
 #include "gemm_epilogue.h"
 #include <stdlib.h>
 
+// Development hooks (A/B kernel variants, ablation branches, s_memtime probes) exist only in a -DTSPO_DEV_HOOKS build
+// (python -m tspo_amd.build --dev); the shipped library carries the small-problem kernel, the 8-wave ring kernel in its
+// production configuration and the 4-wave AGPR kernel of gemm_agpr.hip - nothing that computes deliberately wrong results.
+#ifdef TSPO_DEV_HOOKS
+#define ABL(g, n) ((g).P == -(n))        /* ablation n requested through GemmArgs.P (tools only) */
+#define ABL_LE(g, n) ((g).P <= -(n))
+#else
+#define ABL(g, n) false
+#define ABL_LE(g, n) false
+#endif
+
 namespace {
 
 
@@ -142,6 +153,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 }
 
 
+#ifdef TSPO_DEV_HOOKS
 // ===========================================================================
 // GEMM v2: persistent 256x128x64, 8 waves (4x2, 64x64 each), 3-stage LDS ring
 // (3 x 48 KB) filled by LDS-DMA that stays in flight across barriers (counted
@@ -336,6 +348,8 @@ int launch_gemm_p3(GemmArgs g, hipStream_t st) {
   return tspo::check_launch("gemm_bf16_p3");
 }
 
+#endif  // TSPO_DEV_HOOKS
+
 template <int EPI>
 int launch_gemm_v1(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + GT_BM - 1) / GT_BM;
@@ -369,7 +383,7 @@ __device__ __forceinline__ void g3_stage(const GemmArgs& g, int m0, int n0, int 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.A + (size_t)gr * g.K + koff),
                                      (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
   }
-  if (g.P == -4) return;  // test hook: A half only
+  if (ABL(g, 4)) return;  // dev hook: A half only
 #pragma unroll
   for (int p = 0; p < 8; ++p) {  // W: 32 pieces of 8 rows
     const int piece = j * 8 + p;
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
 
   int i_it = 0, i_kt = 0, i_s = wl;
   int i_m0 = ((i_s / n_per) * npset + pset) * G3_BM, i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
-  int i_rot = g.P != -6 ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
+  int i_rot = !ABL(g, 6) ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
   auto issue_next = [&]() {
     int kt_eff = i_kt + i_rot;
     kt_eff = kt_eff >= nk ? kt_eff - nk : kt_eff;
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
       i_s += nwl;
       i_m0 = ((i_s / n_per) * npset + pset) * G3_BM;
       i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
-      i_rot = g.P != -6 ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
+      i_rot = !ABL(g, 6) ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
     }
   };
   issue_next();
@@ -471,7 +485,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
       asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       if (EARLY == 4) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_vm += t1 - tw0; tw0 = t1; }
       asm volatile("s_barrier" ::: "memory");
-    } else if (g.P != -7) {
+    } else if (!ABL(g, 7)) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       if (EARLY == 4) { const unsigned long long t1 = __builtin_readcyclecounter(); dbg_vm += t1 - tw0; tw0 = t1; }
       asm volatile("s_barrier" ::: "memory");
@@ -481,7 +495,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
     const char* cur = lds + (it & 1) * G3_STAGE;
     if (MODE == 1) {
       // default: every wave issues its own 8 pieces, two behind each group of 16 MFMAs of the first half K-step
-      const bool more = i_it < total_it && g.P > -2;
+      const bool more = i_it < total_it && !ABL_LE(g, 2);
       int kt_eff = i_kt + i_rot;
       kt_eff = kt_eff >= nk ? kt_eff - nk : kt_eff;
       char* nbuf = lds + (i_it & 1) * G3_STAGE;
@@ -580,12 +594,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgs g, int til
           i_s += nwl;
           i_m0 = ((i_s / n_per) * npset + pset) * G3_BM;
           i_n0 = (grp * n_per + i_s % n_per) * G3_BN;
-          i_rot = g.P != -6 ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
+          i_rot = !ABL(g, 6) ? 0 : (int)(((long)(i_s % n_per) * nk) / n_per);
         }
       }
     } else {
-    if (i_it < total_it && g.P != -2) issue_next();
-    if (g.P > -3)
+    if (i_it < total_it && !ABL(g, 2)) issue_next();
+    if (!ABL_LE(g, 3))
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int co = (((kk * 4 + q4) ^ sw) << 4);
@@ -631,6 +645,7 @@ int launch_gemm_p256(GemmArgs g, hipStream_t st) {
 }
 
 
+#ifdef TSPO_DEV_HOOKS
 // ===========================================================================
 // GEMM v4 ("role-split"): same 256x256x64 tile, ring, ownership and epilogue as v3, but the two wave-rows of the
 // workgroup run HALF A K-STEP OUT OF PHASE.  Waves w and w+4 share a SIMD; while one of them issues its 32 MFMAs
@@ -885,6 +900,8 @@ int launch_gemm_w16(GemmArgs g, hipStream_t st) {
   return tspo::check_launch("gemm_bf16_w16");
 }
 
+#endif  // TSPO_DEV_HOOKS
+
 // kernel used for "big" problems: the 4-wave AGPR kernel of gemm_agpr.hip (82) whenever K is a multiple of 128, else the
 // 8-wave LDS-DMA ring kernel (6).  TSPO_GEMM_VARIANT overrides it (dev hook for whole-encoder A/B runs).
 static int default_big_variant(int K) {
@@ -902,31 +919,35 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   const int v = g.variant ? g.variant : (big ? default_big_variant(g.K) : 1);
   g.variant = v;
   if (v == 1) return launch_gemm_v1<EPI>(g, st);
-  if (v == 6) return launch_gemm_p256<EPI, 1, 6>(g, st);     // default: interleaved DMA issue + L2 prefetch of A 6 K-steps ahead
-  if (v == 65) return launch_gemm_p256<EPI, 1, 0>(g, st);    // A/B: no L2 prefetch
-  if (v == 66) return launch_gemm_p256<EPI, 1, 6, 1>(g, st); // A/B: DMA pieces issued in the first quarter of the K-step
-  if (v == 67) return launch_gemm_p256<EPI, 1, 6, 2>(g, st); // A/B: s_setprio(1) around each group of 8 MFMAs
-  if (v == 68) return launch_gemm_p256<EPI, 1, 6, 3>(g, st); // A/B: buffer_load ... lds instead of global_load_lds
+  if (v == 6) return launch_gemm_p256<EPI, 1, 6>(g, st);     // 8-wave LDS-DMA ring: interleaved DMA issue + L2 prefetch of A 6 K-steps ahead
+  if (v >= 80 && v < 90) return tspo::gemm_bf16_agpr(EPI, g, st);   // 4-wave kernel with AGPR accumulators (gemm_agpr.hip)
+#ifdef TSPO_DEV_HOOKS
+  // A/B variants and ablations (tools/bench_gemm.py, tools/probe_gemm_wait.py); several compute wrong results on purpose
+  if (v == 65) return launch_gemm_p256<EPI, 1, 0>(g, st);    // no L2 prefetch
+  if (v == 66) return launch_gemm_p256<EPI, 1, 6, 1>(g, st); // DMA pieces issued in the first quarter of the K-step
+  if (v == 67) return launch_gemm_p256<EPI, 1, 6, 2>(g, st); // s_setprio(1) around each group of 8 MFMAs
+  if (v == 68) return launch_gemm_p256<EPI, 1, 6, 3>(g, st); // buffer_load ... lds instead of global_load_lds
   if (v == 69) return launch_gemm_p256<EPI, 1, 6, 4>(g, st); // timing probe (s_memtime around the per-K-step wait); g.pos = debug buffer
   if (v == 70) return launch_gemm_s256<EPI>(g, st);          // role-split (staggered wave rows)
   if (v == 71) return launch_gemm_w16<EPI>(g, st);           // 16 waves per workgroup (4 per SIMD)
-  if (v >= 80 && v < 90) return tspo::gemm_bf16_agpr(EPI, g, st);   // 4-wave kernels with AGPR accumulators (gemm_agpr.hip)
   if (v == 7) { g.P = -2; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v == 60) { g.P = -7; return launch_gemm_p256<EPI, 1>(g, st); }
-  if (v == 61) return launch_gemm_p256<EPI, 1, 3>(g, st);   // + L2 prefetch of A, 3 K-steps ahead
+  if (v == 61) return launch_gemm_p256<EPI, 1, 3>(g, st);
   if (v == 63) return launch_gemm_p256<EPI, 1, 12>(g, st);
-  if (v == 64) return launch_gemm_p256<EPI, 1, 106>(g, st);  // A and W prefetch, 6 ahead   // compute only, no barrier (timing probe; wrong results)
+  if (v == 64) return launch_gemm_p256<EPI, 1, 106>(g, st);
   if (v == 8) { g.P = -3; return launch_gemm_p256<EPI>(g, st); }
   if (v == 9) { g.P = -4; return launch_gemm_p256<EPI>(g, st); }
   if (v == 30) return launch_gemm_p256<EPI, 0>(g, st);
-  if (v >= 40 && v < 50) { g.ngrp = v - 40; return launch_gemm_p256<EPI, 1>(g, st); }               // forced N groups (0 = auto)
-  if (v >= 50 && v < 60) { g.P = -6; g.ngrp = v - 50; return launch_gemm_p256<EPI, 1>(g, st); }   // K-rotation on, forced N groups   // A/B: all DMA up front, issued by alternating wave rows   // DMA pieces interleaved between MFMA groups
+  if (v >= 40 && v < 50) { g.ngrp = v - 40; return launch_gemm_p256<EPI, 1>(g, st); }
+  if (v >= 50 && v < 60) { g.P = -6; g.ngrp = v - 50; return launch_gemm_p256<EPI, 1>(g, st); }
   if (v >= 10 && v < 20) { g.ngrp = v - 10; return launch_gemm_p3<EPI>(g, st); }
   if (v >= 20 && v < 30) { g.ngrp = v - 20; g.P = -3; return launch_gemm_p3<EPI>(g, st); }
   if (v == 3) { g.P = -1; return launch_gemm_p3<EPI>(g, st); }
   if (v == 4) { g.P = -2; return launch_gemm_p3<EPI>(g, st); }
   if (v == 5) { g.P = -3; return launch_gemm_p3<EPI>(g, st); }
-  return launch_gemm_p3<EPI>(g, st);
+  if (v == 2) return launch_gemm_p3<EPI>(g, st);
+#endif
+  return tspo::set_err(TSPO_EINVAL, "gemm: kernel variant %d is not part of this build", v);
 }
 
 }  // namespace

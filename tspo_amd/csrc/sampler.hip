@@ -75,9 +75,11 @@ struct SelShared {
   uint32_t wsum_gt[SEL_THREADS / 64], wsum_eq[SEL_THREADS / 64];
 };
 
-// keys: LDS array of T keys (if T <= SEL_LDS_KEYS) else nullptr and gkeys used.
-__device__ void select_topk_sorted(const uint32_t* __restrict__ keys, int T, int k, int64_t* __restrict__ out,
-                                   SelShared& sh) {
+// keys(t): order-preserving key of element t - an LDS array when the row fits (T <= SEL_LDS_KEYS), otherwise recomputed
+// from the scores in global memory on each of the 6 passes (long videos: the evaluation harness samples up to 50000
+// frames, gen_id_tspo.py:70).
+template <typename KeyFn>
+__device__ void select_topk_sorted(KeyFn keys, int T, int k, int64_t* __restrict__ out, SelShared& sh) {
   const int tid = threadIdx.x;
   uint32_t prefix = 0, mask = 0, need = (uint32_t)k;
   for (int pass = 3; pass >= 0; --pass) {
@@ -85,7 +87,7 @@ __device__ void select_topk_sorted(const uint32_t* __restrict__ keys, int T, int
     if (tid < 256) sh.hist[tid] = 0;
     __syncthreads();
     for (int t = tid; t < T; t += SEL_THREADS) {
-      const uint32_t key = keys[t];
+      const uint32_t key = keys(t);
       if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
     }
     __syncthreads();
@@ -126,7 +128,7 @@ __device__ void select_topk_sorted(const uint32_t* __restrict__ keys, int T, int
   const int t0 = tid * chunk, t1 = min(T, t0 + chunk);
   int ngt = 0, neq = 0;
   for (int t = t0; t < t1; ++t) {
-    const uint32_t key = keys[t];
+    const uint32_t key = keys(t);
     ngt += key > thr;
     neq += key == thr;
   }
@@ -144,7 +146,7 @@ __device__ void select_topk_sorted(const uint32_t* __restrict__ keys, int T, int
   for (int w = 0; w < wid; ++w) { base_gt += sh.wsum_gt[w]; base_eq += sh.wsum_eq[w]; }
   int pgt = base_gt + sgt - ngt, peq = base_eq + seq - neq;  // exclusive prefixes
   for (int t = t0; t < t1; ++t) {
-    const uint32_t key = keys[t];
+    const uint32_t key = keys(t);
     if (key > thr) {
       out[pgt + min(peq, (int)need)] = (int64_t)t;
       ++pgt;
@@ -156,26 +158,28 @@ __device__ void select_topk_sorted(const uint32_t* __restrict__ keys, int T, int
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void topk_sorted_kernel(const float* __restrict__ scores, int T, int k,
-                                                                  int64_t* __restrict__ idx,
-                                                                  uint32_t* __restrict__ gkeys) {
+                                                                  int64_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
   __shared__ SelShared sh;
   const int b = blockIdx.x;
   const float* s = scores + (size_t)b * T;
-  uint32_t* keys = (T <= SEL_LDS_KEYS) ? lds_keys : (gkeys + (size_t)b * T);
-  for (int t = threadIdx.x; t < T; t += SEL_THREADS) keys[t] = order_key(s[t]);
-  __syncthreads();
-  select_topk_sorted(keys, T, k, idx + (size_t)b * k, sh);
+  if (T <= SEL_LDS_KEYS) {
+    for (int t = threadIdx.x; t < T; t += SEL_THREADS) lds_keys[t] = order_key(s[t]);
+    __syncthreads();
+    const uint32_t* kp = lds_keys;
+    select_topk_sorted([kp](int t) { return kp[t]; }, T, k, idx + (size_t)b * k, sh);
+  } else {
+    select_topk_sorted([s](int t) { return order_key(s[t]); }, T, k, idx + (size_t)b * k, sh);
+  }
 }
 
 extern "C" int tspo_topk_sorted(const float* scores, int B, int T, int k, int64_t* idx, tspo_stream_t stream) {
   TSPO_REQUIRE(scores && idx, "topk_sorted: null pointer");
   TSPO_REQUIRE(B >= 0 && T >= 1 && k >= 1, "topk_sorted: bad dims B=%d T=%d k=%d", B, T, k);
-  TSPO_REQUIRE(T <= SEL_LDS_KEYS, "topk_sorted: T=%d exceeds the LDS-resident limit %d", T, SEL_LDS_KEYS);
   if (B == 0) return TSPO_OK;
   const int ke = k < T ? k : T;
-  hipLaunchKernelGGL(topk_sorted_kernel, dim3(B), dim3(SEL_THREADS), (size_t)T * 4, (hipStream_t)stream, scores, T, ke,
-                     idx, (uint32_t*)nullptr);
+  hipLaunchKernelGGL(topk_sorted_kernel, dim3(B), dim3(SEL_THREADS), T <= SEL_LDS_KEYS ? (size_t)T * 4 : 0,
+                     (hipStream_t)stream, scores, T, ke, idx);
   return tspo::check_launch("topk_sorted");
 }
 
@@ -257,7 +261,10 @@ __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
     lmax = fmaxf(lmax, lv);
   }
   __syncthreads();
-  select_topk_sorted(lds_keys, T, k, idx + ((size_t)b * G + g) * k, sh);
+  {
+    const uint32_t* kp = lds_keys;
+    select_topk_sorted([kp](int t) { return kp[t]; }, T, k, idx + ((size_t)b * G + g) * k, sh);
+  }
 
   if (logp && g == 0) {  // log(softmax(logits)) - no noise (model/utils.py:78)
     lmax = block_max(lmax, red);

@@ -299,19 +299,17 @@ class ClipVitWeights:
         return self._ws
 
 
-FOLD_LAYERNORM = True   # module default of clip_vit_forward(fold_layernorm=None); bench.py --no-ln-fold flips it for A/B runs
-
-
-PRUNE_LAST_LAYER = False   # module default of clip_vit_forward(prune_last_layer=None)
+def _clip_flags(fold_layernorm: bool, prune_last_layer: bool) -> int:
+    return (0 if fold_layernorm else _lib.TSPO_CLIP_NO_LN_FOLD) | (_lib.TSPO_CLIP_PRUNE_LAST if prune_last_layer else 0)
 
 
 def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torch.Tensor] = None,
-                     fold_layernorm: Optional[bool] = None, prune_last_layer: Optional[bool] = None) -> torch.Tensor:
+                     fold_layernorm: bool = True, prune_last_layer: bool = False) -> torch.Tensor:
     """pixels [N,3,H,W] (f32/bf16/f16 normalised, or uint8 raw) -> features f32 [N, proj].
-    fold_layernorm=False keeps the stand-alone LayerNorm passes on large batches too (A/B test hook; small batches
-    never fold).  prune_last_layer=True (opt-in, off by default) evaluates the last transformer block for the class-token
-    row only - the other token rows of that block have no consumer (get_image_features pools row 0), so the features are
-    the same; it is off by default so that the default path executes the full model like the reference does."""
+    fold_layernorm=False keeps the stand-alone LayerNorm passes on large batches too (A/B comparison; small batches
+    never fold).  prune_last_layer=True (opt-in) evaluates the last transformer block for the class-token row only -
+    the other token rows of that block have no consumer (get_image_features pools row 0), so the features are the same;
+    off by default so that the default path executes the full model like the reference does."""
     _need_gpu(pixels)
     if pixels.dtype not in _PIX_DTYPES:
         raise TypeError(f"unsupported pixel dtype {pixels.dtype}")
@@ -322,15 +320,13 @@ def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torc
         raise ValueError(f"pixels must be [N,3,{cfg['image']},{cfg['image']}], got {tuple(px.shape)}")
     ws = w.workspace(N)
     feat = out if out is not None else torch.empty((N, cfg["proj"]), dtype=torch.float32, device=px.device)
-    fold = FOLD_LAYERNORM if fold_layernorm is None else fold_layernorm
-    prune = PRUNE_LAST_LAYER if prune_last_layer is None else prune_last_layer
-    dt = _PIX_DTYPES[px.dtype] | (0 if fold else 0x100) | (0x200 if prune else 0)
-    check(_lib.lib().tspo_clip_vit_forward(C.byref(w.struct), _ptr(px), dt, N, _ptr(feat), _ptr(ws),
-                                           ws.numel(), _stream()), "tspo_clip_vit_forward")
+    check(_lib.lib().tspo_clip_vit_forward_ex(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
+                                              ws.numel(), _stream(), _clip_flags(fold_layernorm, prune_last_layer)),
+          "tspo_clip_vit_forward")
     return feat
 
 
-def clip_vit_profile(w: ClipVitWeights, pixels: torch.Tensor) -> Dict[str, float]:
+def clip_vit_profile(w: ClipVitWeights, pixels: torch.Tensor, fold_layernorm: bool = True) -> Dict[str, float]:
     """One encode with a hipEvent after every launch -> ms per kernel class (profiling; synchronises)."""
     _need_gpu(pixels)
     px = pixels.contiguous()
@@ -338,9 +334,9 @@ def clip_vit_profile(w: ClipVitWeights, pixels: torch.Tensor) -> Dict[str, float
     ws = w.workspace(N)
     feat = torch.empty((N, w.cfg["proj"]), dtype=torch.float32, device=px.device)
     ms = (C.c_float * 6)()
-    dt = _PIX_DTYPES[px.dtype] | (0 if FOLD_LAYERNORM else 0x100)
-    check(_lib.lib().tspo_clip_vit_profile(C.byref(w.struct), _ptr(px), dt, N, _ptr(feat), _ptr(ws),
-                                           ws.numel(), _stream(), ms), "tspo_clip_vit_profile")
+    check(_lib.lib().tspo_clip_vit_profile(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
+                                           ws.numel(), _stream(), ms, _clip_flags(fold_layernorm, False)),
+          "tspo_clip_vit_profile")
     return {"gemm_ms": ms[0], "attn_ms": ms[1], "ln_ms": ms[2], "gather_ms": ms[3], "total_ms": ms[4],
             "gemm_launches": int(ms[5])}
 

@@ -22,10 +22,15 @@ from . import ops
 
 class FrameScorer:
     def __init__(self, clip_weights: ops.ClipVitWeights, selector_flat: torch.Tensor, dim: int = 768, heads: int = 8,
-                 window_size: int = 12, score_tau: float = 0.025):
+                 window_size: int = 12, score_tau: float = 0.025, fold_layernorm: bool = True,
+                 prune_last_layer: bool = False):
         self.clip, self.flat = clip_weights, selector_flat
         self.dim, self.heads, self.window, self.tau = dim, heads, window_size, score_tau
+        self.fold_layernorm, self.prune_last_layer = fold_layernorm, prune_last_layer   # encoder options (ops.clip_vit_forward)
         self._sel_ws = None
+
+    def _encode(self, px: torch.Tensor) -> torch.Tensor:
+        return ops.clip_vit_forward(self.clip, px, fold_layernorm=self.fold_layernorm, prune_last_layer=self.prune_last_layer)
 
     def encode(self, pixels: torch.Tensor, shard_frames: bool = False, group=None) -> torch.Tensor:
         """pixels [B,T,3,H,W] or [N,3,H,W] -> features f32 [.., proj].  shard_frames=True splits the frames of the
@@ -33,12 +38,12 @@ class FrameScorer:
         if shard_frames:
             from .dist import sharded_apply
             flat = pixels.reshape(-1, *pixels.shape[-3:])
-            feats = sharded_apply(lambda px: ops.clip_vit_forward(self.clip, px), flat, group)
+            feats = sharded_apply(self._encode, flat, group)
             return feats.view(*pixels.shape[:-3], -1)
         if pixels.ndim == 5:
             B, T = pixels.shape[:2]
-            return ops.clip_vit_forward(self.clip, pixels.reshape(B * T, *pixels.shape[2:])).view(B, T, -1)
-        return ops.clip_vit_forward(self.clip, pixels)
+            return self._encode(pixels.reshape(B * T, *pixels.shape[2:])).view(B, T, -1)
+        return self._encode(pixels)
 
     def score(self, feats: torch.Tensor, text_features: torch.Tensor, clip_scores: Optional[torch.Tensor] = None):
         """feats [B,T,D], text [B,M,D] -> scores f32 [B,T]."""
