@@ -282,15 +282,16 @@ def main():
         pr = ops.clip_vit_profile(clipw, px, fold_layernorm=not a.no_ln_fold)
         gflop = gemm_flops_per_frame(c) * B * T
         ach = gflop / (pr["gemm_ms"] * 1e-3) / 1e12
-        # HBM-side bytes per GEMM launch: cannot be read from inside the process; taken from the committed PMC passes
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, tools/pmc_traffic.py) when they match this config
+        # HBM-side bytes per GEMM launch cannot be read from inside the process: they come from the committed rocprofv3
+        # --pmc passes (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction) of THIS command
+        # (tools/prof_round.sh -> tools/pmc_traffic.py); the file name says which round's kernels they were taken on.
         traffic, tsrc = None, None
-        tname = "r1_e_gemm_hbm_traffic_T1024.json" if not a.no_ln_fold else "r1_gemm_hbm_traffic_T1024.json"
+        tname = "r2_c_gemm_hbm_traffic_T1024.json" if not a.no_ln_fold else "r1_gemm_hbm_traffic_T1024.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and B * T == 1024:
             try:
                 tj = json.load(open(tpath))
-                traffic, tsrc = tj["hbm_bytes_per_launch_avg"], "profiles/" + tname
+                traffic, tsrc = tj["hbm_bytes_per_launch_avg"], "profiles/" + tname + " (rocprofv3 --pmc passes, not measured in this run)"
             except Exception:
                 pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

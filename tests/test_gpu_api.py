@@ -57,16 +57,26 @@ def test_multimodal_align_module(golden, case, flatten):
 
 
 def test_multimodal_align_bf16_like_reference(golden):
-    """The reference runs the selector in bf16 (gen_id_tspo.py:55): bf16 params/inputs are accepted, outputs keep
-    the input dtype; tolerance = bf16 rounding of inputs and weights (2^-8) amplified by 1/tau."""
+    """The reference runs the selector in bf16 (gen_id_tspo.py:55): bf16 params/inputs are accepted and outputs keep the
+    input dtype.  The HIP path computes in fp32 on the bf16 VALUES and rounds the result once, so against the fp32
+    oracle evaluated on the same bf16-rounded parameters and inputs the only difference is that final rounding:
+    |err| <= 2^-7 |s| (one bf16 ulp; SURVEY 7 'bf16 vs fp32').  Against the fp32-parameter golden the gap is the bf16
+    rounding of weights and inputs themselves (2^-8 each, amplified by 1/tau = 40): reported, bounded loosely."""
     name, T, D, H, w, tau, M, ks = SELECTOR_CASES[0]
     img, txt, clip, state = selector_inputs(name, T, D, M)
     m = make_selector(state, D, H, dtype=torch.bfloat16)
     with torch.no_grad():
         s, h = m(G_(img).bfloat16(), G_(txt).bfloat16(), G_(clip).bfloat16(), window_size=w, score_tau=tau)
     assert s.dtype == torch.bfloat16 and h.dtype == torch.bfloat16
+    r16 = lambda a: T_(a).to(torch.bfloat16).float()
+    s_ref, h_ref = O.selector_forward({k: r16(v) for k, v in state.items()}, r16(img), r16(txt), r16(clip), w, tau, H)
+    got = s.float().cpu()
+    assert bool(((got - s_ref).abs() <= 2.0 ** -7 * s_ref.abs() + 1e-3).all()), (got - s_ref).abs().max()
+    assert bool(((h.float().cpu() - h_ref).abs() <= 2.0 ** -7 * h_ref.abs() + 1e-4).all())
     ref = golden["selector"][f"{name}.scores"]
-    assert np.abs(s.float().cpu().numpy() - ref).max() < 0.05 * np.abs(ref).max() + 0.5
+    gap = np.abs(got.numpy() - ref).max()
+    print(f"\n[bf16 selector] max |score - fp32-parameter golden| = {gap:.3f} (scores up to {np.abs(ref).max():.1f})")
+    assert gap < 0.02 * np.abs(ref).max() + 0.25
 
 
 @pytest.mark.parametrize("case", GUMBEL_CASES[:2], ids=[c[0] for c in GUMBEL_CASES[:2]])

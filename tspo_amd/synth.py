@@ -92,5 +92,31 @@ def clip_vision_state(hidden: int, layers: int, heads: int, mlp: int, patch: int
     return w
 
 
+def clip_vision_state_heavy_tailed(cfg: dict, seed: int = 23, outlier_channels=(7, 300, 911), outlier_gain: float = 50.0,
+                                   gamma_hi: float = 10.0, row_mean: float = 2.0) -> dict:
+    """clip_vision_state with the statistics real ViT-L/14 checkpoints have and smooth N(0, sigma) weights lack:
+    a few residual-stream channels carry values ~50x the rest (the out-proj / fc2 rows and biases that write them are
+    scaled), LayerNorm gains reach 10 on some channels and fall to 0.1 on others, and the residual rows are far from
+    zero-mean (a constant added through the fc2 / out-proj biases).  This is where a LayerNorm folded into bf16 GEMMs
+    (W' = bf16(gamma o W), statistics from the stored bf16 stream) would lose accuracy if it were going to."""
+    w = clip_vision_state(**cfg, seed=seed)
+    hid = cfg["hidden"]
+    oc = np.array([c for c in outlier_channels if c < hid])
+    hi = np.arange(5, hid, 97)          # ~1 % of the channels get gamma x10
+    lo = np.arange(11, hid, 53)         # ~2 % get gamma x0.1
+    p = "vision_model."
+    w[p + "embeddings.position_embedding.weight"][:, oc] *= outlier_gain
+    for l in range(cfg["layers"]):
+        q = f"{p}encoder.layers.{l}."
+        for nm in ("self_attn.out_proj", "mlp.fc2"):
+            w[q + nm + ".weight"][oc, :] *= outlier_gain / 4
+            w[q + nm + ".bias"] = w[q + nm + ".bias"] + np.float32(row_mean / (2 * cfg["layers"]))
+            w[q + nm + ".bias"][oc] *= outlier_gain
+        for nm in ("layer_norm1", "layer_norm2"):
+            w[q + nm + ".weight"][hi] *= gamma_hi
+            w[q + nm + ".weight"][lo] *= 0.1
+    return w
+
+
 CLIP_L14 = dict(hidden=1024, layers=24, heads=16, mlp=4096, patch=14, image=224, proj=768)
 CLIP_TINY = dict(hidden=64, layers=2, heads=4, mlp=128, patch=14, image=28, proj=32)
