@@ -9,6 +9,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 namespace {
 
@@ -339,6 +340,250 @@ __global__ __launch_bounds__(256, 2) void clip_attn_kernel(const bf16_t* __restr
       attn_tiles<1, S_CT>(base, out, Ks, Vt, S, C, ld, f, h, scale, qt, 4, l15, q4);
       qt += 4;
     }
+  }
+}
+
+// ===========================================================================
+// Attention for S = 257 (ViT-L/14 @ 224), head_dim 64: one workgroup per (frame, head), whole K / V of the head staged once
+// in LDS as above, but every wave works on FOUR 16-query tiles at once (64 queries: wave w owns queries 64w .. 64w+63) and
+// walks the keys in three blocks of 96 with an online softmax (running max / sum per query, O rescaled per block).
+// Why: the two-tiles-at-a-time kernel keeps the whole 288-key score row in registers (144 VGPRs), so it cannot take more
+// queries per pass, and it reads one K / V^T fragment from LDS per two MFMAs - with 8 waves per CU that is ~0.75 KB of
+// LDS reads per MFMA, i.e. the LDS pipe (and its 4-way conflicts on the V staging writes) ran as hot as the matrix pipe
+// could have (measured: MFMA busy 22 %, 20 % of LDS cycles conflicts, profiles/r1_e_attn_sq_counters.json).  Here a
+// fragment read feeds FOUR MFMAs, the score registers of a block are 96, and every wave runs exactly one pass.
+// Token 256 - the 257th query, alone in query tile 16 - would cost one wave a whole extra pass; instead waves 0..2 each
+// take ONE key block for that tile (12 + 12 MFMAs) and leave (max, sum, O row) partials in LDS, merged by wave 0.
+// V sub-tiles [32 keys][16 d] are spaced 1056 B apart (not 1024): the 16-byte staging writes of a row then land on 8
+// distinct bank groups instead of 2.
+// ===========================================================================
+#define A4_VSUB 1056
+#define A4_V_BYTES (36 * A4_VSUB)
+#define A4_PART_OFF (AT_KEYS * 128 + A4_V_BYTES)          // partials of the token-256 row: [3][68] floats
+#define A4_LDS_BYTES (A4_PART_OFF + 3 * 68 * 4)
+
+// NQ query tiles starting at tile qt0 against key blocks [b0, b1) (96 keys each).  Returns running max (already times
+// log2e * scale), running sum and the un-normalised O^T accumulators.
+template <int NQ>
+__device__ __forceinline__ void attn257_load_q(const bf16_t* __restrict__ base, size_t ld, int qt0, int l15, int q4,
+                                               bf16x8 (&qf)[NQ][2]) {
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    const int r = (qt0 + n) * 16 + l15;
+    const int rc = r < 257 ? r : 256;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[n][kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)rc * ld + kk * 32 + q4 * 8);
+  }
+}
+
+template <int NQ>
+__device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const char* Ks, const char* Vt, float scale, int b0,
+                                               int b1, int l15, int q4, float (&mrun)[NQ], float (&lrun)[NQ],
+                                               f32x4 (&o)[NQ][4]) {
+  constexpr int S = 257;
+  int voff[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) voff[dt][hh] = dt * A4_VSUB + (hh * 16 + q4 * 4 + (l15 >> 2)) * 32 + (l15 & 3) * 8;
+  const int koff = l15 * 128, ksw = l15 & 7;
+  const float c2 = scale * 1.4426950408889634f;
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    mrun[n] = -INFINITY;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[n][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  union VF { bf16x8 v; s16x4 h2[2]; };
+  f32x4 lsum[NQ];   // running row sums: every row of this accumulator tile is the same sum (all-ones V^T rows)
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) lsum[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  union { bf16x8 v; uint32_t u[4]; } ones;
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;   // bf16 1.0 x 8
+  for (int b = b0; b < b1; ++b) {
+    // ---- S^T = K Q^T for the 6 key tiles of this block (tile 17 does not exist; tile 16 holds only key 256) ----
+    f32x4 sc[NQ][6];
+    const char* kb = Ks + b * 6 * 2048 + koff;
+    bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kb + ((q4 ^ ksw) << 4));
+    bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kb + (((4 + q4) ^ ksw) << 4));
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      bf16x8 nf0 = kf0, nf1 = kf1;
+      if (j + 1 < 6) {   // (rows past S are zero-filled in LDS: always safe to read)
+        nf0 = *reinterpret_cast<const bf16x8*>(kb + (j + 1) * 2048 + ((q4 ^ ksw) << 4));
+        nf1 = *reinterpret_cast<const bf16x8*>(kb + (j + 1) * 2048 + (((4 + q4) ^ ksw) << 4));
+      }
+      const bool live = b * 6 + j <= 16;   // wave-uniform
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        sc[n][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (live) {
+          sc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[n][0], sc[n][j], 0, 0, 0);
+          sc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[n][1], sc[n][j], 0, 0, 0);
+        }
+      }
+      if (b * 6 + j >= 16) {   // key tile 16: only key 256 (row 0 of the tile) exists; tile 17: nothing
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[n][j][r] = ((b * 6 + j) * 16 + q4 * 4 + r) < S ? sc[n][j][r] : -INFINITY;
+      }
+      kf0 = nf0;
+      kf1 = nf1;
+    }
+    // ---- online softmax: lane holds keys (tile j, rows q4*4 + r) of query l15.  The row SUM is not accumulated here:
+    //      it comes out of the P V product below as an extra all-ones row of V^T (one more MFMA per key chunk instead
+    //      of 24 adds and two cross-lane reductions per query tile; the matrix pipe has the slack, the VALU does not) ----
+    float alpha[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      float mx = fmaxf(fmaxf(sc[n][0][0], sc[n][0][1]), fmaxf(sc[n][0][2], sc[n][0][3]));
+#pragma unroll
+      for (int j = 1; j < 6; ++j) mx = fmaxf(fmaxf(mx, fmaxf(sc[n][j][0], sc[n][j][1])), fmaxf(sc[n][j][2], sc[n][j][3]));
+      // max over the 4 lanes of a query (rows of 16 lanes): v_permlane16_swap / v_permlane32_swap, no LDS round trip
+      {
+        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+      }
+      const float mnew = fmaxf(mrun[n], mx * c2);
+      alpha[n] = __builtin_amdgcn_exp2f(mrun[n] - mnew);   // first block: exp2(-inf) = 0 (o and l are 0 anyway)
+      mrun[n] = mnew;
+      const f32x2 c2v = {c2, c2}, nm = {-mnew, -mnew};
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const f32x2 lo = {sc[n][j][0], sc[n][j][1]}, hi = {sc[n][j][2], sc[n][j][3]};
+        const f32x2 tl = lo * c2v + nm, th = hi * c2v + nm;   // v_pk_fma_f32
+        sc[n][j][0] = __builtin_amdgcn_exp2f(tl[0]); sc[n][j][1] = __builtin_amdgcn_exp2f(tl[1]);
+        sc[n][j][2] = __builtin_amdgcn_exp2f(th[0]); sc[n][j][3] = __builtin_amdgcn_exp2f(th[1]);
+      }
+      lsum[n] *= alpha[n];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[n][dt] *= alpha[n];
+    }
+    // ---- O^T += V^T P^T over the 3 key chunks (32 keys) of this block ----
+    const char* vb = Vt + b * 3 * 4 * A4_VSUB;
+    auto ldv = [&](int step) {   // step = c * 4 + dt
+      VF f;
+      const int c = step >> 2, dt = step & 3;
+      f.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + voff[dt][0] + c * 4 * A4_VSUB));
+      f.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + voff[dt][1] + c * 4 * A4_VSUB));
+      return f;
+    };
+    VF vcur = ldv(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      union { bf16x8 v; uint32_t u[4]; } pf[NQ];
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        pf[n].u[0] = pack_bf16x2(sc[n][2 * c][0], sc[n][2 * c][1]);
+        pf[n].u[1] = pack_bf16x2(sc[n][2 * c][2], sc[n][2 * c][3]);
+        pf[n].u[2] = pack_bf16x2(sc[n][2 * c + 1][0], sc[n][2 * c + 1][1]);
+        pf[n].u[3] = pack_bf16x2(sc[n][2 * c + 1][2], sc[n][2 * c + 1][3]);
+        lsum[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pf[n].v, lsum[n], 0, 0, 0);   // row sums of the bf16 P
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int step = c * 4 + dt;
+        VF vnext = vcur;
+        if (step + 1 < 12) vnext = ldv(step + 1);
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) o[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcur.v, pf[n].v, o[n][dt], 0, 0, 0);
+        vcur = vnext;
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) lrun[n] = lsum[n][0];
+}
+
+__global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int C,
+                                                              float scale) {
+  constexpr int S = 257;
+  __shared__ __attribute__((aligned(16))) char lds[A4_LDS_BYTES];
+  char* Ks = lds;
+  char* Vt = lds + AT_KEYS * 128;
+  float* part = reinterpret_cast<float*>(lds + A4_PART_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  // (frame, head) of this workgroup: consecutive items go to the SAME XCD (blockIdx % 8 observed = XCD; speed only), so the
+  // 16 heads of a frame - the 16 x 128-byte slices of each 6 KB token row of qkv - are read through one L2 at about the
+  // same time instead of being scattered over all eight
+  const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+  const int item = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
+  const int h = item % (int)gridDim.x;
+  const size_t f = item / (int)gridDim.x;
+  const size_t ld = (size_t)3 * C;
+  const bf16_t* base = qkv + f * S * ld + (size_t)h * 64;
+  bf16x8 qf4[4][2];
+  {   // stage K (swizzled 128-byte rows) and V (row-major [32 keys][16 d] sub-tiles): all loads in flight, then the writes
+    uint4 kv[9], vv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int id = tid + i * 256;
+      const int row = id >> 3, c = id & 7;
+      const int rc = row < S ? row : S - 1;
+      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + C + c * 8);
+      vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + 2 * C + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int id = tid + i * 256;
+      const int row = id >> 3, c = id & 7;
+      const uint4 z = {0u, 0u, 0u, 0u};
+      const uint4 k4 = row < S ? kv[i] : z, v4 = row < S ? vv[i] : z;
+      *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = k4;
+      *reinterpret_cast<uint4*>(Vt + ((row >> 5) * 4 + (c >> 1)) * A4_VSUB + (row & 31) * 32 + (c & 1) * 16) = v4;
+      if (i == 0) attn257_load_q<4>(base, ld, wid * 4, l15, q4, qf4);   // this wave's Q fragments, behind the staging loads
+    }
+  }
+  __syncthreads();
+
+  {   // this wave's 64 queries
+    float m4[4], l4[4];
+    f32x4 o4[4][4];
+    attn257_blocks<4>(qf4, Ks, Vt, scale, 0, 3, l15, q4, m4, l4, o4);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int qrow = (wid * 4 + n) * 16 + l15;
+      const float inv = 1.f / l4[n];
+      bf16_t* orow = out + (f * S + qrow) * (size_t)C + (size_t)h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o4[n][dt][0] * inv, o4[n][dt][1] * inv);
+        pk.y = pack_bf16x2(o4[n][dt][2] * inv, o4[n][dt][3] * inv);
+        *reinterpret_cast<uint2*>(orow + dt * 16 + q4 * 4) = pk;
+      }
+    }
+  }
+  // token 256 (query tile 16, row 0): waves 0..2 take one key block each
+  if (wid < 3) {
+    float m1[1], l1[1];
+    f32x4 o1[1][4];
+    bf16x8 qf1[1][2];
+    attn257_load_q<1>(base, ld, 16, l15, q4, qf1);
+    attn257_blocks<1>(qf1, Ks, Vt, scale, wid, wid + 1, l15, q4, m1, l1, o1);
+    if (l15 == 0) {
+      float* pw = part + wid * 68;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[dt * 16 + q4 * 4 + r] = o1[0][dt][r];
+      if (q4 == 0) { pw[64] = m1[0]; pw[65] = l1[0]; }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {   // lane d merges the three partials of output column d
+    const float ma = part[64], mb = part[68 + 64], mc = part[136 + 64];
+    const float m = fmaxf(ma, fmaxf(mb, mc));
+    const float wa = __builtin_amdgcn_exp2f(ma - m), wb = __builtin_amdgcn_exp2f(mb - m), wc = __builtin_amdgcn_exp2f(mc - m);
+    const float l = part[65] * wa + part[68 + 65] * wb + part[136 + 65] * wc;
+    const float ov = (part[tid] * wa + part[68 + tid] * wb + part[136 + tid] * wc) / l;
+    const float on = __shfl_down(ov, 1, 64);
+    if ((tid & 1) == 0)
+      *reinterpret_cast<uint32_t*>(out + (f * S + 256) * (size_t)C + (size_t)h * 64 + tid) = pack_bf16x2(ov, on);
   }
 }
 
@@ -753,7 +998,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       pooled_done = true;
       break;
     }
-    if (S == 257) hipLaunchKernelGGL(clip_attn_kernel<257>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
+    if (S == 257) hipLaunchKernelGGL(clip_attn257_kernel, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
     else hipLaunchKernelGGL(clip_attn_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     if (int e = tspo::check_launch("clip_attn")) return e;
     prof.tick(PK_ATTN);
