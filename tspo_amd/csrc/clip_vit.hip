@@ -498,6 +498,8 @@ __device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const 
   for (int n = 0; n < NQ; ++n) lrun[n] = lsum[n][0];
 }
 
+// ABL (dev builds only): 1 = staging + stores without the attention math, 2 = the math without the global loads
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int C,
                                                               float scale) {
   constexpr int S = 257;
@@ -524,6 +526,11 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
       const int id = tid + i * 256;
       const int row = id >> 3, c = id & 7;
       const int rc = row < S ? row : S - 1;
+      if (ABL == 2) {
+        kv[i] = uint4{0x3c003c00u + id, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        vv[i] = kv[i];
+        continue;
+      }
       kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + C + c * 8);
       vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + 2 * C + c * 8);
     }
@@ -543,6 +550,19 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
   {   // this wave's 64 queries
     float m4[4], l4[4];
     f32x4 o4[4][4];
+    if (ABL == 1) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        l4[n] = 1.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const uint4 t = *reinterpret_cast<const uint4*>(Ks + (n * 4 + dt) * 1024 + tid * 16);
+          union { bf16x8 v; uint32_t u[4]; } qq;
+          qq.v = qf4[n][dt & 1];
+          o4[n][dt] = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w ^ qq.u[0])};
+        }
+      }
+    } else
     attn257_blocks<4>(qf4, Ks, Vt, scale, 0, 3, l15, q4, m4, l4, o4);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -559,6 +579,7 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
     }
   }
   // token 256 (query tile 16, row 0): waves 0..2 take one key block each
+  if (ABL == 1) return;
   if (wid < 3) {
     float m1[1], l1[1];
     f32x4 o1[1][4];
@@ -998,7 +1019,13 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       pooled_done = true;
       break;
     }
-    if (S == 257) hipLaunchKernelGGL(clip_attn257_kernel, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
+#ifdef TSPO_DEV_HOOKS
+    static const int attn_abl = getenv("TSPO_ATTN_ABL") ? atoi(getenv("TSPO_ATTN_ABL")) : 0;
+    if (S == 257 && attn_abl == 1) hipLaunchKernelGGL(clip_attn257_kernel<1>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
+    else if (S == 257 && attn_abl == 2) hipLaunchKernelGGL(clip_attn257_kernel<2>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
+    else
+#endif
+    if (S == 257) hipLaunchKernelGGL(clip_attn257_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
     else hipLaunchKernelGGL(clip_attn_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     if (int e = tspo::check_launch("clip_attn")) return e;
     prof.tick(PK_ATTN);
