@@ -253,7 +253,7 @@ def main():
         sc, _ = scorer.score(feats_res, txt)
         out["idx2"] = ops.topk_sorted(sc, k)
 
-    sel_sec = timed(select_step, max(a.steps, 20), 3) / max(a.steps, 20)
+    sel_sec = timed(select_step, max(a.steps, 200), 3) / max(a.steps, 200)
     assert torch.equal(out["idx2"], out["idx"])
 
     # ---- rollouts / s (policy side of one TSPO step, configs[2]) --------------
@@ -267,12 +267,12 @@ def main():
         clip = ops.clip_scores(ttxt, feats)
         rew = (torch.rand(Bt, G, generator=gen, device=dev) > 0.5).float() + torch.rand(Bt, G, generator=gen, device=dev)
         trainer = PolicyTrainer(flat.clone())
-        rsec = timed(lambda: trainer.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 20), 3)
-        rollouts = Bt * G * world * max(a.steps, 20) / rsec
+        rsec = timed(lambda: trainer.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 200), 3)
+        rollouts = Bt * G * world * max(a.steps, 200) / rsec
         # opt-in split-precision selector GEMMs (NOT the headline number): see DESIGN.md, TSPO_SEL_BF16X3
         trainer_x3 = PolicyTrainer(flat.clone(), gemm_precision="bf16x3")
-        xsec = timed(lambda: trainer_x3.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 20), 3)
-        rollouts_x3 = Bt * G * world * max(a.steps, 20) / xsec
+        xsec = timed(lambda: trainer_x3.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 200), 3)
+        rollouts_x3 = Bt * G * world * max(a.steps, 200) / xsec
 
     # ---- roofline of the dominant kernel (bf16 MFMA GEMM), live HIP-event timing --------------------------
     roof = None

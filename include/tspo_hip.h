@@ -105,6 +105,12 @@ int tspo_pg_grad_logits(const float* logp, const int64_t* idx, const float* adv,
                         int B, int G, int T, int k, float scale,
                         float* dlogits, float* loss, tspo_stream_t stream);
 
+/* The two calls above in one launch (rewards -> advantages -> dlogits); `adv`
+ * [B,G] is still written (the trainer logs it).  Same results bit for bit.  */
+int tspo_grpo_pg_grad(const float* rewards, const float* logp, const int64_t* idx,
+                      int B, int G, int T, int k, float eps, float scale,
+                      float* adv, float* dlogits, float* loss, tspo_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Temporal scoring head ("selector", MultiModal_Align)
  * ------------------------------------------------------------------------ */
@@ -184,6 +190,17 @@ int tspo_grad_norm_scale(const float* grad, size_t n, float pre_scale, float max
 int tspo_adamw_step(float* param, const float* grad, float* m, float* v, size_t n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     float grad_scale, const float* d_grad_scale, tspo_stream_t stream);
+
+/* tspo_grad_norm_scale + tspo_adamw_step in two launches instead of three
+ * (HF Trainer: clip_grad_norm_(max_grad_norm) then optimizer.step()): the
+ * AdamW kernel finishes the norm reduction itself and applies
+ * coefficient * pre_scale to the gradient on the fly (grad is not modified).
+ * out2 f32 [2] = (||g||_2, applied scale); workspace >= 1024 floats;
+ * buffers 16-byte aligned.                                                  */
+int tspo_adamw_clip_step(float* param, const float* grad, float* m, float* v, size_t n,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float pre_scale, float max_norm, float* out2,
+                         void* workspace, size_t workspace_bytes, tspo_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * CLIP ViT vision tower + projection  (frame encoder)

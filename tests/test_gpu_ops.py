@@ -277,6 +277,43 @@ def test_adamw_matches_oracle_on_identical_inputs():
         np.testing.assert_allclose(v.cpu().numpy(), vo.numpy(), rtol=1e-5, atol=1e-12)
 
 
+def test_fused_policy_entries_match_the_separate_ones():
+    """tspo_grpo_pg_grad == tspo_grpo_advantage + tspo_pg_grad_logits bit for bit; tspo_adamw_clip_step ==
+    tspo_grad_norm_scale + tspo_adamw_step to rounding (its 16-byte-wide partial sums add in a different order)."""
+    B, G, T, k = 3, 8, 700, 16
+    scores = G_(synth.normal((B, T), 71, 1.0))
+    out = ops.gumbel_topk(scores, k, G, seed=5)
+    rew = G_(synth.uniform((B, G), 72).reshape(B, G).astype(np.float32))
+    adv = ops.grpo_advantage(rew)
+    dl, loss = ops.pg_grad_logits(out["logp"], out["idx"], adv, scale=0.25)
+    adv2, dl2, loss2 = ops.grpo_pg_grad(rew, out["logp"], out["idx"], scale=0.25)
+    assert torch.equal(adv, adv2) and torch.equal(dl, dl2) and torch.equal(loss, loss2)
+    n = 100003 * 4
+    p0 = synth.normal((n,), 81, 0.05)
+    pa, ma, va = G_(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb, mb, vb = G_(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        g = G_(synth.normal((n,), 82 + step, 3e-3))
+        ns = ops.grad_norm_scale(g, n, 0.5, 1.0)
+        ops.adamw_step(pa, g, ma, va, n, lr=5e-4, step=step, weight_decay=0.01, d_grad_scale=ns)
+        ns2 = ops.adamw_clip_step(pb, g, mb, vb, n, lr=5e-4, step=step, weight_decay=0.01, pre_scale=0.5, max_norm=1.0)
+        assert ns[1].item() < 0.5                                      # the clip is active
+        np.testing.assert_allclose(ns2.cpu().numpy(), ns.cpu().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(pb.cpu().numpy(), pa.cpu().numpy(), rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(mb.cpu().numpy(), ma.cpu().numpy(), rtol=1e-5, atol=1e-10)
+        np.testing.assert_allclose(vb.cpu().numpy(), va.cpu().numpy(), rtol=1e-5, atol=1e-13)
+    # ragged tail (n % 4 != 0) of the vectorised kernels
+    n = 1003
+    g = G_(synth.normal((n,), 90, 1e-2))
+    pa, ma, va = G_(p0[:n]), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb, mb, vb = G_(p0[:n]), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ns = ops.grad_norm_scale(g, n, 1.0, 0.0)
+    ops.adamw_step(pa, g, ma, va, n, lr=1e-3, step=1, d_grad_scale=ns)
+    ns2 = ops.adamw_clip_step(pb, g, mb, vb, n, lr=1e-3, step=1, max_norm=0.0)
+    np.testing.assert_allclose(ns2.cpu().numpy(), ns.cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(pb.cpu().numpy(), pa.cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
 # every head-width instantiation of the MFMA banded attention (16..128), ragged T (not a multiple of 16, shorter than
 # the window), odd / maximal windows, and the shapes that must fall back to the generic kernels (w > 17, head width 24)
 SHAPE_CASES = [
@@ -288,6 +325,10 @@ SHAPE_CASES = [
     ("hd96_w18_generic", 1, 40, 768, 8, 18),
     ("hd24_generic", 1, 20, 192, 8, 12),
     ("hd64_h4_T300", 1, 300, 256, 4, 12),
+    # D % 384 == 0: the data-gradient + weight-gradient launches are merged and the bias column sums come out of the
+    # weight-gradient kernels; several split planes, a ragged last chunk, rows past M in the last 64-row tile
+    ("hd96_T300_merged", 2, 300, 768, 8, 12),
+    ("hd48_D384_merged", 1, 70, 384, 8, 12),
 ]
 
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "tspo_gumbel_topk": (_i, [_p, _p, _u64, _u64, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "tspo_grpo_advantage": (_i, [_p, _i, _i, _f, _p, _p]),
     "tspo_pg_grad_logits": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p]),
+    "tspo_grpo_pg_grad": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p]),
     "tspo_selector_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "tspo_selector_forward": (_i, [C.POINTER(SelectorWeights), _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _sz, _p]),
     "tspo_selector_backward": (_i, [C.POINTER(SelectorWeights), _p, _p, _p, _i, _i, _i, _i, _i, _i, _f,
@@ -62,6 +63,7 @@ SIGNATURES = {
                                        C.POINTER(SelectorGrads), _p, _sz, _p, _i]),
     "tspo_grad_norm_scale": (_i, [_p, _sz, _f, _f, _p, _p, _sz, _p]),
     "tspo_adamw_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _p, _p]),
+    "tspo_adamw_clip_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _f, _p, _p, _sz, _p]),
     "tspo_clip_workspace_bytes": (_sz, [C.POINTER(ClipConfig), _i]),
     "tspo_clip_vit_forward": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p]),
     "tspo_clip_vit_forward_ex": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p, _i]),

@@ -5,6 +5,8 @@
 #include "common.h"
 #include <stdarg.h>
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
 namespace tspo {
 static thread_local char g_err[512] = "";
 char* err_buf() { return g_err; }
@@ -384,6 +386,67 @@ extern "C" int tspo_pg_grad_logits(const float* logp, const int64_t* idx, const 
   return tspo::check_launch("pg_grad_logits");
 }
 
+// The two steps above in one launch (what PolicyTrainer.backward issues): every block recomputes its prompt's G
+// advantages (first wave, same reduction as grpo_advantage_kernel -> same bits) instead of reading them back.
+__global__ __launch_bounds__(256) void grpo_pg_grad_kernel(const float* __restrict__ rewards, const float* __restrict__ logp,
+                                                           const int64_t* __restrict__ idx, int G, int T, int k, float eps,
+                                                           float scale, float* __restrict__ adv_out,
+                                                           float* __restrict__ dlogits, float* __restrict__ loss) {
+  extern __shared__ __attribute__((aligned(16))) int lds_idx[];  // G*k ints then G floats
+  float* a = reinterpret_cast<float*>(lds_idx + (size_t)G * k);
+  const int b = blockIdx.x, tid = threadIdx.x;   // blockIdx.y: 256-frame slice of the row
+  for (int i = tid; i < G * k; i += 256) lds_idx[i] = (int)idx[(size_t)b * G * k + i];
+  if (tid < 64) {
+    const float* rb = rewards + (size_t)b * G;
+    float s = 0.f;
+    for (int g = tid; g < G; g += 64) s += rb[g];
+    const float mean = wave_sum(s) / (float)G;
+    float q = 0.f;
+    for (int g = tid; g < G; g += 64) { const float d = rb[g] - mean; q += d * d; }
+    const float sd = sqrtf(wave_sum(q) / (float)(G - 1));
+    for (int g = tid; g < G; g += 64) {
+      const float v = (rb[g] - mean) / (sd + eps);
+      a[g] = v;
+      if (blockIdx.y == 0) adv_out[(size_t)b * G + g] = v;
+    }
+  }
+  __syncthreads();
+  float sumA = 0.f;
+  for (int g = 0; g < G; ++g) sumA += a[g];
+  const float invk = 1.f / (float)k, invG = 1.f / (float)G;
+  const int t = blockIdx.y * 256 + tid;
+  if (t < T) {
+    const float p = expf(logp[(size_t)b * T + t]);
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const int* my = lds_idx + g * k;
+      int lo = 0, hi = k - 1;
+      bool hit = false;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int v = my[mid];
+        if (v == t) { hit = true; break; }
+        if (v < t) lo = mid + 1; else hi = mid - 1;
+      }
+      acc += a[g] * ((hit ? invk : 0.f) - p);
+    }
+    dlogits[(size_t)b * T + t] = -invG * acc * scale;
+  }
+  if (loss && tid == 0 && blockIdx.y == 0) loss[b] = -sumA * invG;
+}
+
+extern "C" int tspo_grpo_pg_grad(const float* rewards, const float* logp, const int64_t* idx, int B, int G, int T, int k,
+                                 float eps, float scale, float* adv, float* dlogits, float* loss, tspo_stream_t stream) {
+  TSPO_REQUIRE(rewards && logp && idx && adv && dlogits, "grpo_pg_grad: null pointer");
+  TSPO_REQUIRE(B >= 0 && G >= 1 && T >= 1 && k >= 1 && k <= T, "grpo_pg_grad: bad dims B=%d G=%d T=%d k=%d", B, G, T, k);
+  const size_t lds = (size_t)G * k * 4 + (size_t)G * 4;
+  TSPO_REQUIRE(lds <= 64 * 1024, "grpo_pg_grad: G*k=%d too large for LDS", G * k);
+  if (B == 0) return TSPO_OK;
+  hipLaunchKernelGGL(grpo_pg_grad_kernel, dim3(B, (T + 255) / 256), dim3(256), lds, (hipStream_t)stream, rewards, logp, idx, G,
+                     T, k, eps, scale, adv, dlogits, loss);
+  return tspo::check_launch("grpo_pg_grad");
+}
+
 // ---------------------------------------------------------------------------
 // grad norm (two-stage, deterministic) and AdamW
 #define NORM_BLOCKS 512
@@ -443,6 +506,94 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     pi -= step_size * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
+}
+
+// AdamW that finishes the gradient-norm reduction itself: every block adds the <= NORM_BLOCKS partial sums of squares
+// (same order as norm_final_kernel -> same bits), derives the clip coefficient and applies it; block 0 also publishes
+// (norm, coefficient * pre_scale) for the caller's logging.
+__global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                                                         float b1, float b2, float eps, float wd, float bc1, float rsq_bc2,
+                                                         const float* __restrict__ partial, int np, float pre_scale,
+                                                         float max_norm, float* __restrict__ out2) {
+  __shared__ float red[32];
+  __shared__ float gs_sh;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf(s);
+    float c = 1.f;
+    if (max_norm > 0.f) c = fminf(1.f, max_norm / (nrm + 1e-6f));
+    gs_sh = c * pre_scale;
+    if (blockIdx.x == 0) { out2[0] = nrm; out2[1] = c * pre_scale; }
+  }
+  __syncthreads();
+  const float gs = gs_sh;
+  const float step_size = lr / bc1;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i] * gs;
+    f32x4 p4 = reinterpret_cast<f32x4*>(p)[i] * (1.f - lr * wd);
+    f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      m4[c] = b1 * m4[c] + (1.f - b1) * g4[c];
+      v4[c] = b2 * v4[c] + (1.f - b2) * g4[c] * g4[c];
+      p4[c] -= step_size * (m4[c] / (sqrtf(v4[c]) * rsq_bc2 + eps));
+    }
+    reinterpret_cast<f32x4*>(p)[i] = p4;
+    reinterpret_cast<f32x4*>(m)[i] = m4;
+    reinterpret_cast<f32x4*>(v)[i] = v4;
+  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    pi -= step_size * (mi / (sqrtf(vi) * rsq_bc2 + eps));
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// 16-byte loads; same partial layout as sqsum_partial_kernel
+__global__ __launch_bounds__(256) void sqsum_partial4_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+  __shared__ float red[32];
+  float s = 0.f;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+extern "C" int tspo_adamw_clip_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, float pre_scale, float max_norm,
+                                    float* out2, void* workspace, size_t workspace_bytes, tspo_stream_t stream) {
+  TSPO_REQUIRE(param && grad && m && v && out2 && workspace, "adamw_clip_step: null pointer");
+  TSPO_REQUIRE(step >= 1, "adamw_clip_step: step must be >= 1");
+  TSPO_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+               "adamw_clip_step: buffers must be 16-byte aligned");
+  if (workspace_bytes < NORM_BLOCKS * sizeof(float))
+    return tspo::set_err(TSPO_EWORKSPACE, "adamw_clip_step: workspace %zu < %zu", workspace_bytes,
+                         NORM_BLOCKS * sizeof(float));
+  if (n == 0) return TSPO_OK;
+  int nb = (int)((n / 4 + 255) / 256);
+  if (nb > NORM_BLOCKS) nb = NORM_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(sqsum_partial4_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grad, n, (float*)workspace);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  size_t ab = (n / 4 + 255) / 256;
+  if (ab > 2048) ab = 2048;
+  if (ab < 1) ab = 1;
+  hipLaunchKernelGGL(adamw_clip_kernel, dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), (const float*)workspace, nb, pre_scale,
+                     max_norm, out2);
+  return tspo::check_launch("adamw_clip_step");
 }
 
 extern "C" int tspo_adamw_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1,

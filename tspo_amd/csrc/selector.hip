@@ -140,23 +140,26 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 // One workgroup = 64 x (32*WN) outputs, NWM x 2 waves of (64/NWM) x (16*WN); 3-deep ring with counted vmcnt waits.
 // WN = 3 (64x96 tiles) is used when N % 96 == 0: for D = 768 that makes BT=2048 x 768 exactly 256 workgroups (one
 // per CU) and x 2304 exactly 3 per CU, instead of 1.5 / 4.5 with 64x64 tiles, and gives 48 MFMAs per barrier.
+template <int WN, int NT_NST>
+constexpr int nt_lds_bytes() { return NT_NST * (8 + 4 * WN) * 1024; }
+
+// (body of the kernel: also instantiated inside dgrad_wgrad_kernel, which runs it next to a weight-gradient tile set)
 template <int EPI, int WN, int NWM, int NT_NST, int SPLIT>
-__global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                                    const float* __restrict__ bias,
-                                                                    const float* __restrict__ R, float* __restrict__ C,
-                                                                    int M, int N, int K) {
+__device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __restrict__ A, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ R,
+                                                     float* __restrict__ C, int M, int N, int K, int bx, int by) {
   constexpr int NW = NWM * 2;                  // waves: NWM along M x 2 along N
   constexpr int MI = 4 / NWM;                  // 16-row tiles per wave (64 rows / NWM / 16)
   constexpr int BN = 32 * WN;                  // W rows per slab
   constexpr int PIECES = 8 + BN / 8;           // 1 KB DMA pieces per slab (A: 8, W: BN/8)
   constexpr int PW_HI = (PIECES + NW - 1) / NW, PW_LO = PIECES / NW;   // first NHI waves move PW_HI pieces, the rest PW_LO
   constexpr int NHI = PIECES - PW_LO * NW;     // (0 when it divides evenly)
-  constexpr int SLAB = PIECES * 1024;
-  __shared__ __attribute__((aligned(16))) char lds[NT_NST * SLAB];   // ring of (A 64x128 B | W BNx128 B); the only LDS object
+  constexpr int SLAB = PIECES * 1024;          // ring of (A 64x128 B | W BNx128 B)
+  static_assert(NT_NST * SLAB == nt_lds_bytes<WN, NT_NST>(), "LDS size");
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, q = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+  const int m0 = by * 64, n0 = bx * BN;
   const int nk = K >> 5;
   const int rin = lane >> 3, slot = lane & 7;
   const bool hi = NHI == 0 || wid < NHI;
@@ -282,6 +285,15 @@ __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float*
         }
       }
     }
+}
+
+template <int EPI, int WN, int NWM, int NT_NST, int SPLIT>
+__global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ R, float* __restrict__ C,
+                                                                    int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) char lds[nt_lds_bytes<WN, NT_NST>()];   // the only LDS object
+  gemm_f32_nt_lds_body<EPI, WN, NWM, NT_NST, SPLIT>(lds, A, W, bias, R, C, M, N, K, blockIdx.x, blockIdx.y);
 }
 
 template <int EPI, int SPLIT>
@@ -833,9 +845,30 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict_
 }
 
 // dh_t = (ds_t / tau / M) * sum_m [ e_m/den_m - (h.e_m) |e_m| / (den_m^2 |h|) h ]
+// The launch also carries the two weight transposes the data-gradient GEMMs need (W1^T, W2^T; blocks past n_score, 32x32
+// tiles): they are independent of the score gradient and far too small for a launch of their own.
 __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict__ h, const float* __restrict__ txt,
                                                         const float* __restrict__ dscores, float* __restrict__ dh,
-                                                        int B, int T, int D, int M, float tau) {
+                                                        int B, int T, int D, int M, float tau, int n_score,
+                                                        const float* __restrict__ w1, float* __restrict__ w1t,
+                                                        const float* __restrict__ w2, float* __restrict__ w2t) {
+  if ((int)blockIdx.x >= n_score) {
+    __shared__ float tile[32][33];
+    const int tpr = (D + 31) / 32;
+    int tb = blockIdx.x - n_score;
+    const bool second = tb >= tpr * tpr;
+    tb -= second ? tpr * tpr : 0;
+    const float* in = second ? w2 : w1;
+    float* out = second ? w2t : w1t;
+    const int bx = (tb % tpr) * 32, by = (tb / tpr) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8)
+      if (by + r < D && bx + tx < D) tile[r][tx] = in[(size_t)(by + r) * D + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+      if (bx + r < D && by + tx < D) out[(size_t)(bx + r) * D + by + tx] = tile[tx][r];
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * T) return;
@@ -935,47 +968,62 @@ __global__ __launch_bounds__(256) void gemm_f32_tn_kernel(const float* __restric
 // SIMD waiting on HBM/L2 latency.  Fragment reads are conflict-free ds_read_b128 (16 lanes = 256 contiguous bytes).
 #define TN_ROWS 16
 #define TN_NST 4
-__global__ __launch_bounds__(256, 2) void gemm_f32_tn_lds_kernel(const float* __restrict__ dY, const float* __restrict__ X,
-                                                                 float* __restrict__ Cp, int Mrows, int NI, int NJ,
-                                                                 int chunk) {
-  __shared__ __attribute__((aligned(16))) char lds[TN_NST * 16384];   // per stage: A 16x512 B | B 16x512 B
+// NW = 4: 2x2 waves of 64x64 (the stand-alone kernel); NW = 8: 2x4 waves of 64x32 (inside dgrad_wgrad_kernel, whose
+// workgroups have 512 threads).  Same contraction order per output element either way.  `cpart` (optional): the
+// workgroups of feature-tile column 0 also emit the column sums of their dY rows (= this split's bias-gradient
+// partial, cpart[s * cstride + i]) from the fragments they read anyway.
+template <int NW>
+__device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __restrict__ dY, const float* __restrict__ X,
+                                                     float* __restrict__ Cp, float* __restrict__ cpart, int cstride,
+                                                     int Mrows, int NI, int NJ, int chunk, int bj, int bi, int s) {
+  constexpr int WJ = NW / 2;            // waves along j
+  constexpr int CB = 4 / (WJ / 2);      // interleaved 16-column tiles per wave along j: 4 (64 columns) or 2 (32 columns)
+  constexpr int PW = 8 / NW;            // DMA instructions per wave, operand and slab (2 rows each, 16 rows per slab)
+  typedef float fb_t __attribute__((ext_vector_type(CB)));
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, q = lane >> 4;
-  const int wi = wid >> 1, wj = wid & 1;
-  const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
-  const int s = blockIdx.z;
+  const int wi = wid / WJ, wj = wid % WJ;
+  const int i0 = bi * 128, j0 = bj * 128;
   const int mb = s * chunk, me = min(Mrows, mb + chunk);
-  f32x4 acc[4][4];
+  f32x4 acc[4][CB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < CB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const bool want_cs = cpart != nullptr && bj == 0 && wj == 0;   // wave-uniform
   const int nst = me > mb ? (me - mb + TN_ROWS - 1) / TN_ROWS : 0;
   const int rlast = me > mb ? me - 1 : mb;
   const int prow = lane >> 5, pcol = (lane & 31) << 2;
-  auto stage = [&](int t) {   // wave wid moves rows 4*wid..4*wid+3 of both slabs (2 rows per DMA instruction)
+  auto stage = [&](int t) {   // wave wid moves rows 2*PW*wid .. 2*PW*wid + 2*PW-1 of both slabs
     char* buf = lds + (t & (TN_NST - 1)) * 16384;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int rr = wid * 4 + p * 2 + prow;
+    for (int p = 0; p < PW; ++p) {
+      const int rr = (wid * PW + p) * 2 + prow;
       int r = mb + t * TN_ROWS + rr;
       r = r < rlast ? r : rlast;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + (size_t)r * NI + i0 + pcol),
-                                       (__attribute__((address_space(3))) void*)(buf + (wid * 4 + p * 2) * 512), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(buf + (wid * PW + p) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)r * NJ + j0 + pcol),
-                                       (__attribute__((address_space(3))) void*)(buf + 8192 + (wid * 4 + p * 2) * 512), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(buf + 8192 + (wid * PW + p) * 1024), 16, 0, 0);
     }
   };
 #pragma unroll
   for (int t = 0; t < TN_NST - 1; ++t)
     if (t < nst) stage(t);
-  const int offA = (wi * 64 + 4 * l15) * 4, offB = 8192 + (wj * 64 + 4 * l15) * 4;
+  const int offA = (wi * 64 + 4 * l15) * 4, offB = 8192 + (wj * 16 * CB + CB * l15) * 4;
   for (int t = 0; t < nst; ++t) {
-    // slabs t+1, t+2 (4 DMA instructions each per wave) may stay in flight
+    // slabs t+1, t+2 (2*PW DMA instructions each per wave) may stay in flight
     const int ahead = min(TN_NST - 2, nst - 1 - t);
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PW == 2) {
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();   // slab t visible to all waves; everyone is done with slab t-1 -> its slot is free
     if (t + TN_NST - 1 < nst) stage(t + TN_NST - 1);
     const char* cur = lds + (t & (TN_NST - 1)) * 16384;
@@ -984,11 +1032,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tn_lds_kernel(const float* __
       const int m = ks * 4 + q;
       const float keep = (mb + t * TN_ROWS + m < me) ? 1.f : 0.f;
       const f32x4 a = *reinterpret_cast<const f32x4*>(cur + offA + m * 512) * keep;
-      const f32x4 b = *reinterpret_cast<const f32x4*>(cur + offB + m * 512);
+      const fb_t b = *reinterpret_cast<const fb_t*>(cur + offB + m * 512);
+      if (want_cs) csum += a;
 #pragma unroll
       for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ca], b[cb], acc[ca][cb], 0, 0, 0);
+        for (int cb = 0; cb < CB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ca], b[cb], acc[ca][cb], 0, 0, 0);
     }
   }
   float* cp = Cp + (size_t)s * NI * NJ;
@@ -997,9 +1046,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tn_lds_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + wi * 64 + 4 * (q * 4 + r) + ca;
-      f32x4 v = {acc[ca][0][r], acc[ca][1][r], acc[ca][2][r], acc[ca][3][r]};
-      *reinterpret_cast<f32x4*>(cp + (size_t)i * NJ + j0 + wj * 64 + 4 * l15) = v;
+      fb_t v;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) v[cb] = acc[ca][cb][r];
+      *reinterpret_cast<fb_t*>(cp + (size_t)i * NJ + j0 + wj * 16 * CB + CB * l15) = v;
     }
+  if (want_cs) {   // rows m = 4*ks + q were summed per lane: add the four q groups (fixed order -> deterministic)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = csum[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      csum[c] = v;
+    }
+    if (q == 0) *reinterpret_cast<f32x4*>(cpart + (size_t)s * cstride + i0 + wi * 64 + 4 * l15) = csum;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_tn_lds_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                                 float* __restrict__ Cp, float* __restrict__ cpart,
+                                                                 int cstride, int Mrows, int NI, int NJ, int chunk) {
+  __shared__ __attribute__((aligned(16))) char lds[TN_NST * 16384];   // per stage: A 16x512 B | B 16x512 B
+  gemm_f32_tn_lds_body<4>(lds, dY, X, Cp, cpart, cstride, Mrows, NI, NJ, chunk, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// One launch = the data-gradient GEMM of a linear layer (dX = dY W: the 64x96-tile kernel above, 512-thread workgroups)
+// AND the weight-gradient tiles of the layer after it (the two are independent).  Each alone fills the 256 CUs with one
+// workgroup per CU and leaves the matrix pipes idle across its barriers; the hardware dispatches the data-gradient
+// workgroups first and the weight-gradient ones into the second slot of every CU.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void dgrad_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                            const float* __restrict__ R, float* __restrict__ C, int M,
+                                                            int N, int K, int n_nt,
+                                                            const float* __restrict__ dY, const float* __restrict__ X,
+                                                            float* __restrict__ Cp, float* __restrict__ cpart, int cstride,
+                                                            int NI, int NJ, int chunk) {
+  constexpr int LDS = nt_lds_bytes<3, 3>() > TN_NST * 16384 ? nt_lds_bytes<3, 3>() : TN_NST * 16384;
+  __shared__ __attribute__((aligned(16))) char lds[LDS];
+  const int b = blockIdx.x;
+  if (b < n_nt) {
+    const int nx = N / 96;
+    gemm_f32_nt_lds_body<EPI, 3, 4, 3, 0>(lds, A, W, nullptr, R, C, M, N, K, b % nx, b / nx);
+  } else {
+    const int t = b - n_nt, tj = NJ >> 7, ti = NI >> 7;
+    gemm_f32_tn_lds_body<8>(lds, dY, X, Cp, cpart, cstride, M, NI, NJ, chunk, t % tj, (t / tj) % ti, t / (tj * ti));
+  }
 }
 
 // Split-precision (bf16x3) version of the weight-gradient GEMM: same 128x128 tile / 4 waves of 64x64 / interleaved
@@ -1141,22 +1232,6 @@ __global__ __launch_bounds__(256) void colsum3_kernel(const float* __restrict__ 
   if (ty == 0) part[(size_t)blockIdx.y * 5 * D + ccol] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
-// two square transposes in one launch (blockIdx.z picks the matrix)
-__global__ __launch_bounds__(256) void transpose2_kernel(const float* __restrict__ in0, float* __restrict__ out0,
-                                                         const float* __restrict__ in1, float* __restrict__ out1, int R,
-                                                         int Cc) {
-  __shared__ float tile[32][33];
-  const float* in = blockIdx.z ? in1 : in0;
-  float* out = blockIdx.z ? out1 : out0;
-  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int r = ty; r < 32; r += 8)
-    if (by + r < R && bx + tx < Cc) tile[r][tx] = in[(size_t)(by + r) * Cc + bx + tx];
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8)
-    if (bx + r < Cc && by + tx < R) out[(size_t)(bx + r) * R + by + tx] = tile[tx][r];
-}
-
 // cos(text_b, feat_bt) like torch.nn.CosineSimilarity(dim=-1, eps=1e-8)
 __global__ __launch_bounds__(256) void clip_scores_kernel(const float* __restrict__ txt, const float* __restrict__ f,
                                                           float* __restrict__ out, int B, int T, int D, int M) {
@@ -1295,17 +1370,30 @@ extern "C" int tspo_selector_forward_ex(const tspo_selector_weights* w, const fl
 }
 
 namespace {
-int weight_grad(const float* dY, const float* X, float* part, int BT, int NI, int NJ, const SelWs& s, hipStream_t st,
-                bool split) {
+// cpart != nullptr: the LDS kernel also writes this split's bias-gradient partials; returns through *fused whether it did
+int weight_grad(const float* dY, const float* X, float* part, float* cpart, int cstride, int BT, int NI, int NJ,
+                const SelWs& s, hipStream_t st, bool split) {
   const int chunk = ((BT + s.S - 1) / s.S + 3) / 4 * 4;
   dim3 grid((NJ + 127) / 128, (NI + 127) / 128, s.S);
   if (split && NI % 128 == 0 && NJ % 128 == 0)
     hipLaunchKernelGGL(gemm_f32_tn_split_kernel, grid, dim3(256), 0, st, dY, X, part, BT, NI, NJ, chunk);
   else if (NI % 128 == 0 && NJ % 128 == 0)
-    hipLaunchKernelGGL(gemm_f32_tn_lds_kernel, grid, dim3(256), 0, st, dY, X, part, BT, NI, NJ, chunk);
+    hipLaunchKernelGGL(gemm_f32_tn_lds_kernel, grid, dim3(256), 0, st, dY, X, part, cpart, cstride, BT, NI, NJ, chunk);
   else
     hipLaunchKernelGGL(gemm_f32_tn_kernel, grid, dim3(256), 0, st, dY, X, part, BT, NI, NJ, chunk);
   return tspo::check_launch("selector weight_grad");
+}
+
+// dX = mask?(dY W) together with the weight gradient dYw^T Xw of another layer in one launch (see dgrad_wgrad_kernel)
+template <int EPI>
+int dgrad_with_wgrad(const float* dY, const float* Wt, const float* R, float* dX, int BT, int N, int K, const float* dYw,
+                     const float* Xw, float* part, float* cpart, int cstride, int NI, int NJ, const SelWs& s,
+                     hipStream_t st) {
+  const int chunk = ((BT + s.S - 1) / s.S + 3) / 4 * 4;
+  const int n_nt = (N / 96) * ((BT + 63) / 64), n_tn = (NI / 128) * (NJ / 128) * s.S;
+  hipLaunchKernelGGL((dgrad_wgrad_kernel<EPI>), dim3(n_nt + n_tn), dim3(512), 0, st, dY, Wt, R, dX, BT, N, K, n_nt, dYw, Xw,
+                     part, cpart, cstride, NI, NJ, chunk);
+  return tspo::check_launch("selector dgrad+wgrad");
 }
 }  // namespace
 
@@ -1323,20 +1411,33 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
     return tspo::set_err(TSPO_EWORKSPACE, "selector_backward: workspace %zu < %zu", workspace_bytes, s.bytes);
   hipStream_t st = (hipStream_t)stream;
   const int BT = B * T;
-  dim3 tg((D + 31) / 32, (D + 31) / 32, 2);
-  hipLaunchKernelGGL(transpose2_kernel, tg, dim3(256), 0, st, w->w1, s.w1t, w->w2, s.w2t, D, D);
   const size_t DD = (size_t)D * D;
   float* part_w2 = s.part;
   float* part_w1 = s.part + (size_t)s.S * DD;
   float* part_qkv = s.part + (size_t)s.S * 2 * DD;
   // score -> dh2
-  hipLaunchKernelGGL(score_bwd_kernel, dim3((BT + 3) / 4), dim3(256), 0, st, s.h2, txt, dscores, s.dh2, B, T, D, M, tau);
-  // mlp.2
-  if (int e = weight_grad(s.dh2, s.h1, part_w2, BT, D, D, s, st, split)) return e;
-  if (int e = launch_gemm_nt<EPI_MASK>(s.dh2, s.w2t, nullptr, s.h1, s.dh1, BT, D, D, st, split)) return e;
-  // mlp.0
-  if (int e = weight_grad(s.dh1, s.ctx, part_w1, BT, D, D, s, st, split)) return e;
-  if (int e = launch_gemm_nt<EPI_NONE>(s.dh1, s.w1t, nullptr, nullptr, s.dctx, BT, D, D, st, split)) return e;
+  const int n_score = (BT + 3) / 4, tpr = (D + 31) / 32;
+  hipLaunchKernelGGL(score_bwd_kernel, dim3(n_score + 2 * tpr * tpr), dim3(256), 0, st, s.h2, txt, dscores, s.dh2, B, T, D, M,
+                     tau, n_score, w->w1, s.w1t, w->w2, s.w2t);
+  // exact-fp32 path with 128-divisible D: bias-gradient column sums come out of the weight-gradient kernels, and each of
+  // the two DxD weight gradients shares a launch with the data-gradient GEMM that does not depend on it
+  const bool fused = !split && D % 128 == 0 && D % 96 == 0;
+  const int cstride = 5 * D;
+  if (fused) {
+    // mlp.2 data gradient (dh1) || mlp.2 weight gradient (dh2^T h1)
+    if (int e = dgrad_with_wgrad<EPI_MASK>(s.dh2, s.w2t, s.h1, s.dh1, BT, D, D, s.dh2, s.h1, part_w2, s.cpart, cstride, D, D, s,
+                                           st)) return e;
+    // mlp.0 data gradient (dctx) || mlp.0 weight gradient (dh1^T ctx)
+    if (int e = dgrad_with_wgrad<EPI_NONE>(s.dh1, s.w1t, nullptr, s.dctx, BT, D, D, s.dh1, s.ctx, part_w1, s.cpart + D, cstride,
+                                           D, D, s, st)) return e;
+  } else {
+    // mlp.2
+    if (int e = weight_grad(s.dh2, s.h1, part_w2, nullptr, 0, BT, D, D, s, st, split)) return e;
+    if (int e = launch_gemm_nt<EPI_MASK>(s.dh2, s.w2t, nullptr, s.h1, s.dh1, BT, D, D, st, split)) return e;
+    // mlp.0
+    if (int e = weight_grad(s.dh1, s.ctx, part_w1, nullptr, 0, BT, D, D, s, st, split)) return e;
+    if (int e = launch_gemm_nt<EPI_NONE>(s.dh1, s.w1t, nullptr, nullptr, s.dctx, BT, D, D, st, split)) return e;
+  }
   // banded attention
   const long pairs = (long)BT * H;
   const unsigned pb = (unsigned)((pairs + 7) / 8);
@@ -1347,11 +1448,16 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
     hipLaunchKernelGGL(band_attn_bwd_kv_kernel, dim3(pb), dim3(256), 0, st, s.qkv, s.P, s.dS, s.dctx, s.dqkv, B, T, D, H,
                        window);
   // q/k/v projections
-  if (int e = weight_grad(s.dqkv, s.xpe, part_qkv, BT, 3 * D, D, s, st, split)) return e;
-  // bias grads: column sums of dh2 | dh1 | dqkv, then every split reduction (3 weights + 3 biases) in one launch
-  const int rows_per = (BT + s.CS - 1) / s.CS;
-  hipLaunchKernelGGL(colsum3_kernel, dim3(5 * D / 64, s.CS), dim3(256), 0, st, s.dh2, s.dh1, s.dqkv, s.cpart, BT, D,
-                     rows_per);
+  if (int e = weight_grad(s.dqkv, s.xpe, part_qkv, fused ? s.cpart + 2 * D : nullptr, cstride, BT, 3 * D, D, s, st, split))
+    return e;
+  // bias grads: column sums of dh2 | dh1 | dqkv (fused above, or CS row slabs here), then every split reduction
+  // (3 weights + 3 biases) in one launch
+  const int bias_planes = fused ? s.S : s.CS;
+  if (!fused) {
+    const int rows_per = (BT + s.CS - 1) / s.CS;
+    hipLaunchKernelGGL(colsum3_kernel, dim3(5 * D / 64, s.CS), dim3(256), 0, st, s.dh2, s.dh1, s.dqkv, s.cpart, BT, D,
+                       rows_per);
+  }
   RedSegs L;
   const float* parts[RED_SEGS] = {part_w2, part_w1, part_qkv, s.cpart, s.cpart + D, s.cpart + 2 * D};
   float* outs[RED_SEGS] = {g->w2, g->w1, g->wqkv, g->b2, g->b1, g->bqkv};
@@ -1364,7 +1470,7 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
     L.end[i] = run;
     // weight partial planes are n apart; bias partial planes are 5*D apart (one row of the concatenated column sums)
     L.n[i] = i < 3 ? ns[i] : 5ull * D;
-    L.S[i] = i < 3 ? s.S : s.CS;
+    L.S[i] = i < 3 ? s.S : bias_planes;
   }
   L.count = RED_SEGS;
   int nb = (int)((run / 4 + 255) / 256);

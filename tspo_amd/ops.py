@@ -114,6 +114,24 @@ def pg_grad_logits(logp: torch.Tensor, idx: torch.Tensor, adv: torch.Tensor, sca
     return dl, loss
 
 
+def grpo_pg_grad(rewards: torch.Tensor, logp: torch.Tensor, idx: torch.Tensor, scale: float = 1.0, eps: float = 1e-4):
+    """grpo_advantage + pg_grad_logits in one launch: rewards [B,G], logp [B,T], idx [B,G,k] ->
+    (adv [B,G], dlogits [B,T], loss [B]); identical results."""
+    _need_gpu(rewards, logp, idx)
+    r, lp = _f32c(rewards), _f32c(logp)
+    ix = idx.to(torch.int64).contiguous()
+    B, T = lp.shape
+    _, G, k = ix.shape
+    if tuple(r.shape) != (B, G):
+        raise ValueError(f"rewards {tuple(r.shape)} do not match idx {tuple(ix.shape)}")
+    adv = torch.empty_like(r)
+    dl = torch.empty_like(lp)
+    loss = torch.empty((B,), dtype=torch.float32, device=lp.device)
+    check(_lib.lib().tspo_grpo_pg_grad(_ptr(r), _ptr(lp), _ptr(ix), B, G, T, k, float(eps), float(scale), _ptr(adv), _ptr(dl),
+                                       _ptr(loss), _stream()), "tspo_grpo_pg_grad")
+    return adv, dl, loss
+
+
 # ---------------------------------------------------------------------------
 # selector (flat parameter bucket; reference key names are views into it)
 # ---------------------------------------------------------------------------
@@ -229,6 +247,22 @@ def adamw_step(param, grad, m, v, n: int, lr: float, step: int, beta1=0.9, beta2
     check(_lib.lib().tspo_adamw_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, float(lr), float(beta1), float(beta2),
                                      float(eps), float(weight_decay), int(step), float(grad_scale), _ptr(d_grad_scale),
                                      _stream()), "tspo_adamw_step")
+
+
+def adamw_clip_step(param, grad, m, v, n: int, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                    pre_scale: float = 1.0, max_norm: float = 1.0, out: Optional[torch.Tensor] = None,
+                    ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """grad_norm_scale + adamw_step (two launches instead of three) -> device tensor [2] = (||g||, applied scale)."""
+    _need_gpu(param, grad, m, v, out, ws)
+    if out is None:
+        out = torch.empty((2,), dtype=torch.float32, device=grad.device)
+    if ws is None:
+        ws = torch.empty((2048,), dtype=torch.uint8, device=grad.device)
+    check(_lib.lib().tspo_adamw_clip_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, float(lr), float(beta1),
+                                          float(beta2), float(eps), float(weight_decay), int(step), float(pre_scale),
+                                          float(max_norm), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+          "tspo_adamw_clip_step")
+    return out
 
 
 # ---------------------------------------------------------------------------

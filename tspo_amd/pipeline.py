@@ -171,8 +171,7 @@ class PolicyTrainer:
         if self._micro >= self.grad_accum_steps:
             raise RuntimeError("gradient accumulation boundary reached: call optimizer_step() before another backward()")
         B = feats.shape[0]
-        adv = ops.grpo_advantage(rewards)
-        dlog, loss = ops.pg_grad_logits(logp, idx, adv, scale=1.0 / (B * self.grad_accum_steps))
+        adv, dlog, loss = ops.grpo_pg_grad(rewards, logp, idx, scale=1.0 / (B * self.grad_accum_steps))
         if self._micro == 0:
             target = self.grad
         else:
@@ -187,7 +186,7 @@ class PolicyTrainer:
         ctx.consumed = True
         self._ws_pool.append(ctx.ws)
         ctx.ws = None
-        return {"loss": loss * self.grad_accum_steps, "advantages": adv}
+        return {"loss": loss if self.grad_accum_steps == 1 else loss * self.grad_accum_steps, "advantages": adv}
 
     def at_boundary(self) -> bool:
         return self._micro >= self.grad_accum_steps
@@ -202,12 +201,11 @@ class PolicyTrainer:
         world = int(self.reduce_fn(self.grad, self.n_train, self.pg))      # RCCL over xGMI (one collective)
         # the bucket now holds the SUM over ranks: its norm is world x the norm of the mean gradient, so clipping the
         # mean at max_norm == clipping the sum at world*max_norm, then scaling by 1/world (no extra pass over the bucket)
-        ns = ops.grad_norm_scale(self.grad, self.n_train, 1.0 / world, self.max_norm * world, out=self._norm_out,
-                                 ws=self._norm_ws)
         use_lr = lr if lr is not None else self.current_lr()
         self.step_no += 1
-        ops.adamw_step(self.flat, self.grad, self.m, self.v, self.n_train, use_lr, self.step_no, self.betas[0],
-                       self.betas[1], self.eps, self.wd, 1.0, ns)
+        ns = ops.adamw_clip_step(self.flat, self.grad, self.m, self.v, self.n_train, use_lr, self.step_no, self.betas[0],
+                                 self.betas[1], self.eps, self.wd, pre_scale=1.0 / world, max_norm=self.max_norm * world,
+                                 out=self._norm_out, ws=self._norm_ws)
         self._micro = 0
         self._param_version += 1
         return {"grad_norm_scale": ns, "lr": use_lr, "world": world}
