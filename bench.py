@@ -103,7 +103,7 @@ def flat_from_state(st, D, device):
     return flat
 
 
-def cpu_baseline(T, k, budget_s=20.0):
+def cpu_baseline(T, k):
     """The oracle (CPU restatement of the reference path, oracle/tspo_oracle.py) on the host cores, bounded sample:
     CLIP-L on n frames (frames are independent -> per-frame cost), selector + top-k at the full T."""
     from oracle import tspo_oracle as O
@@ -123,8 +123,7 @@ def cpu_baseline(T, k, budget_s=20.0):
         return time.perf_counter() - t0
 
     enc(4)                                     # warm-up (thread pool, allocator)
-    t16 = enc(16)
-    n = int(max(16, min(256, (budget_s - 3.0) / (t16 / 16) // 16 * 16)))
+    n = 64                                     # encode timed at N = 64 frames, scaled linearly
     tn = enc(n)
     feats = torch.randn(T, 768, generator=g)
     txt = torch.randn(1, 768, generator=g)
@@ -148,6 +147,25 @@ def cpu_baseline(T, k, budget_s=20.0):
             "cpu_model": model, "host_logical_cpus": os.cpu_count(),
             "sample": f"oracle (torch-CPU fp32): CLIP-L/14 on {n} frames in {tn:.2f}s + selector/top-k at T={T} in "
                       f"{tsel * 1e3:.1f}ms, {cores} threads"}
+
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+POLICY_STEP_LAUNCHES = 17       # profiles/r2_d_kernel_trace_policy_step_fp32.txt: 7 rollout + 8 backward + 2 optimizer
+
+
+def policy_step_roofline(B: int, T: int, D: int, step_s: float) -> dict:
+    """What bounds one policy step (selector forward + G rollouts + backward + clip + AdamW): its fp32 MFMA GEMMs.
+    Forward: q|k|v [BT,D]x[D,3D] + two [BT,D]x[D,D]; backward: two data gradients [BT,D]x[D,D] and the three weight
+    gradients (D*D, D*D, 3*D*D outputs over BT rows).  Everything else (banded attention, scores, Gumbel top-k, advantage,
+    AdamW over 2.95 M parameters) is < 2 % of the FLOPs but ~28 % of the time: 17 dependent launches of a few us each."""
+    bt = B * T
+    fwd = 2.0 * bt * D * (3 * D + D + D)
+    bwd = 2.0 * bt * D * (D + D) + 2.0 * bt * D * (D + D + 3 * D)
+    ach = (fwd + bwd) / step_s / 1e12
+    return {"bound": "mfma", "unit": "TFLOP/s", "dtype": "f32", "gemm_flop_per_step": fwd + bwd,
+            "achieved": round(ach, 1), "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "launches_per_step": POLICY_STEP_LAUNCHES, "us_per_step": round(step_s * 1e6, 1),
+            "note": "achieved = GEMM FLOPs / WHOLE step time (the non-GEMM launches are inside the denominator)"}
 
 
 def main():
@@ -325,6 +343,7 @@ def main():
                         "(~1e-5 relative error vs exact fp32); not used for `rollouts_per_s`"},
             "rollouts_config": None if rollouts is None else {"workload": "policy step (reward LLM excluded); default = configs[2]",
                                                               "B": Bt, "T": Tt, "G": G, "k": kt},
+            "rollouts_roofline": None if rollouts is None else policy_step_roofline(Bt, Tt, 768, Bt * G * world / rollouts),
             "encode_tflops": round((gemm_flops_per_frame(c) + attn_flops_per_frame(c)) * fps / 1e12, 1),
             "optional_pruned_last_block": None if pruned_fps is None else {
                 "frames_scored_per_s": round(pruned_fps, 2),

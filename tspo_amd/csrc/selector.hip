@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void gemm_f32_tn_kernel(const float* __restric
 // workgroups have 512 threads).  Same contraction order per output element either way.  `cpart` (optional): the
 // workgroups of feature-tile column 0 also emit the column sums of their dY rows (= this split's bias-gradient
 // partial, cpart[s * cstride + i]) from the fragments they read anyway.
-template <int NW>
+template <int NW, int NST>
 __device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __restrict__ dY, const float* __restrict__ X,
                                                      float* __restrict__ Cp, float* __restrict__ cpart, int cstride,
                                                      int Mrows, int NI, int NJ, int chunk, int bj, int bi, int s) {
@@ -996,7 +996,7 @@ __device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __r
   const int rlast = me > mb ? me - 1 : mb;
   const int prow = lane >> 5, pcol = (lane & 31) << 2;
   auto stage = [&](int t) {   // wave wid moves rows 2*PW*wid .. 2*PW*wid + 2*PW-1 of both slabs
-    char* buf = lds + (t & (TN_NST - 1)) * 16384;
+    char* buf = lds + (t % NST) * 16384;
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
       const int rr = (wid * PW + p) * 2 + prow;
@@ -1009,12 +1009,12 @@ __device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __r
     }
   };
 #pragma unroll
-  for (int t = 0; t < TN_NST - 1; ++t)
+  for (int t = 0; t < NST - 1; ++t)
     if (t < nst) stage(t);
   const int offA = (wi * 64 + 4 * l15) * 4, offB = 8192 + (wj * 16 * CB + CB * l15) * 4;
   for (int t = 0; t < nst; ++t) {
     // slabs t+1, t+2 (2*PW DMA instructions each per wave) may stay in flight
-    const int ahead = min(TN_NST - 2, nst - 1 - t);
+    const int ahead = min(NST - 2, nst - 1 - t);
     if (PW == 2) {
       if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1025,8 +1025,8 @@ __device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __r
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // slab t visible to all waves; everyone is done with slab t-1 -> its slot is free
-    if (t + TN_NST - 1 < nst) stage(t + TN_NST - 1);
-    const char* cur = lds + (t & (TN_NST - 1)) * 16384;
+    if (t + NST - 1 < nst) stage(t + NST - 1);
+    const char* cur = lds + (t % NST) * 16384;
 #pragma unroll
     for (int ks = 0; ks < TN_ROWS / 4; ++ks) {
       const int m = ks * 4 + q;
@@ -1063,11 +1063,13 @@ __device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __r
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_f32_tn_lds_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+// (3-deep ring here: 48 KB and <= 168 registers let three workgroups share a CU, so the 108 x S tiles of the q/k/v weight
+// gradient - 756 for BT = 2048 - are resident at once instead of leaving a half-empty second round)
+__global__ __launch_bounds__(256, 3) void gemm_f32_tn_lds_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                                  float* __restrict__ Cp, float* __restrict__ cpart,
                                                                  int cstride, int Mrows, int NI, int NJ, int chunk) {
-  __shared__ __attribute__((aligned(16))) char lds[TN_NST * 16384];   // per stage: A 16x512 B | B 16x512 B
-  gemm_f32_tn_lds_body<4>(lds, dY, X, Cp, cpart, cstride, Mrows, NI, NJ, chunk, blockIdx.x, blockIdx.y, blockIdx.z);
+  __shared__ __attribute__((aligned(16))) char lds[3 * 16384];   // per stage: A 16x512 B | B 16x512 B
+  gemm_f32_tn_lds_body<4, 3>(lds, dY, X, Cp, cpart, cstride, Mrows, NI, NJ, chunk, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // One launch = the data-gradient GEMM of a linear layer (dX = dY W: the 64x96-tile kernel above, 512-thread workgroups)
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(512, 2) void dgrad_wgrad_kernel(const float* __rest
     gemm_f32_nt_lds_body<EPI, 3, 4, 3, 0>(lds, A, W, nullptr, R, C, M, N, K, b % nx, b / nx);
   } else {
     const int t = b - n_nt, tj = NJ >> 7, ti = NI >> 7;
-    gemm_f32_tn_lds_body<8>(lds, dY, X, Cp, cpart, cstride, M, NI, NJ, chunk, t % tj, (t / tj) % ti, t / (tj * ti));
+    gemm_f32_tn_lds_body<8, TN_NST>(lds, dY, X, Cp, cpart, cstride, M, NI, NJ, chunk, t % tj, (t / tj) % ti, t / (tj * ti));
   }
 }
 
@@ -1262,6 +1264,9 @@ struct SelWs {  // workspace layout shared by forward and backward
 // at one-SIMD-per-wave speed, so the makespan is set by how evenly tiles*S workgroups fill 256 CUs: pick the S (chunk
 // of >= 128 rows, at most 16 partial planes) that wastes the least of the last "round" for both the DxD and 3DxD GEMMs.
 int split_for(int BT, int D) {
+#ifdef TSPO_DEV_HOOKS
+  if (const char* e = getenv("TSPO_SEL_SPLIT")) return atoi(e);
+#endif
   int smax = BT / 128;
   smax = smax < 1 ? 1 : (smax > 16 ? 16 : smax);
   const int tiles = ((D + 127) / 128) * ((D + 127) / 128);
