@@ -71,7 +71,8 @@ def test_shipped_library_has_no_dev_hooks():
         assert l.tspo_gemm_bf16(p, p, p, None, p, _lib.TSPO_BF16, 4096, 4096, 1024, variant << 8, None) == -1
         assert b"not part of this build" in l.tspo_last_error()
     blob = open(_lib.LIB_PATH, "rb").read()
-    for name in (b"gemm_bf16_p3_kernel", b"gemm_bf16_s256_kernel", b"gemm_bf16_w16_kernel"):
+    for name in (b"gemm_bf16_p3_kernel", b"gemm_bf16_s256_kernel", b"gemm_bf16_w16_kernel", b"clip_attn257p_kernel",
+                 b"TSPO_GEMM_VARIANT", b"TSPO_ATTN_ABL", b"TSPO_SEL_SPLIT", b"getenv"):   # no env-driven behaviour either
         assert name not in blob, name
     assert b"gemm_bf16_a7_kernel" in blob and b"gemm_bf16_p256_kernel" in blob
 

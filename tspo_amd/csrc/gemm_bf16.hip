@@ -903,13 +903,16 @@ int launch_gemm_w16(GemmArgs g, hipStream_t st) {
 #endif  // TSPO_DEV_HOOKS
 
 // kernel used for "big" problems: the 4-wave AGPR kernel of gemm_agpr.hip (82) whenever K is a multiple of 128, else the
-// 8-wave LDS-DMA ring kernel (6).  TSPO_GEMM_VARIANT overrides it (dev hook for whole-encoder A/B runs).
+// 8-wave LDS-DMA ring kernel (6).  In --dev builds TSPO_GEMM_VARIANT overrides it (whole-encoder A/B runs); the shipped
+// library reads no environment variables.
 static int default_big_variant(int K) {
+#ifdef TSPO_DEV_HOOKS
   static const int forced = [] {
     const char* e = getenv("TSPO_GEMM_VARIANT");
     return e && atoi(e) > 0 ? atoi(e) : 0;
   }();
   if (forced) return forced;
+#endif
   return (K % 128 == 0) ? 82 : 6;
 }
 
