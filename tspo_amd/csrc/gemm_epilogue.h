@@ -58,7 +58,8 @@ __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], co
     orow = (size_t)f * (g.P + 1) + prow;
   }
   const float rs = rst.x, mu = rst.y;   // rstd, -mean * rstd
-  float ssum = 0.f, ssq = 0.f;
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t st_lo[4], st_hi[4];   // GE_RESID_ST: the 16 values of this lane as stored (bf16-rounded), kept for the second pass
   uint2 pk[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
@@ -88,27 +89,35 @@ __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], co
     } else {
       pk[ni].x = pack_bf16x2(v[0], v[1]);
       pk[ni].y = pack_bf16x2(v[2], v[3]);
-      if (EPI == GE_RESID_ST && ok) {   // statistics of the values as stored (bf16-rounded): what the next GEMM reads
-        const float r0 = __uint_as_float(pk[ni].x << 16), r1 = __uint_as_float(pk[ni].x & 0xffff0000u);
-        const float r2 = __uint_as_float(pk[ni].y << 16), r3 = __uint_as_float(pk[ni].y & 0xffff0000u);
-        ssum += (r0 + r1) + (r2 + r3);
+      if (EPI == GE_RESID_ST) {   // statistics of the values as stored (bf16-rounded): what the next GEMM reads
+        const float keep = ok ? 1.f : 0.f;   // (FULL: constant 1)
+        st_lo[ni] = f32x2_t{__uint_as_float(pk[ni].x << 16), __uint_as_float(pk[ni].x & 0xffff0000u)} * keep;
+        st_hi[ni] = f32x2_t{__uint_as_float(pk[ni].y << 16), __uint_as_float(pk[ni].y & 0xffff0000u)} * keep;
       }
     }
   }
   if (EPI == GE_RESID_ST) {   // the row's 64 columns of this slice live in the 4 lanes that share l15
-    // per-slice (mean, centred sum of squares): two passes over the 16 stored values of this lane, so the later
-    // combination of the N/64 slices (Chan et al.) is as robust as a two-pass LayerNorm
-    ssum += __shfl_xor(ssum, 16, 64);
-    ssum += __shfl_xor(ssum, 32, 64);
-    const float smean = ssum * (1.0f / 64.0f);
+    // per-slice (mean, centred sum of squares): two passes over the 16 stored values of this lane (packed adds / fmas),
+    // so the later combination of the N/64 slices (Chan et al.) is as robust as a two-pass LayerNorm.  The 4-lane sums
+    // use v_permlane16/32_swap: no LDS round trip (ds_bpermute) in the middle of the epilogue.
+    auto sum4 = [](float x) {
+      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+      const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    };
+    f32x2_t s2 = (st_lo[0] + st_hi[0]) + (st_lo[1] + st_hi[1]);
+    s2 += (st_lo[2] + st_hi[2]) + (st_lo[3] + st_hi[3]);
+    const float smean = sum4(s2[0] + s2[1]) * (1.0f / 64.0f);
+    const f32x2_t mm = {smean, smean};
+    f32x2_t q2 = {0.f, 0.f};
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      const float d0 = __uint_as_float(pk[ni].x << 16) - smean, d1 = __uint_as_float(pk[ni].x & 0xffff0000u) - smean;
-      const float d2 = __uint_as_float(pk[ni].y << 16) - smean, d3 = __uint_as_float(pk[ni].y & 0xffff0000u) - smean;
-      ssq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      const f32x2_t d0 = st_lo[ni] - mm, d1 = st_hi[ni] - mm;
+      q2 = d0 * d0 + q2;
+      q2 = d1 * d1 + q2;
     }
-    ssq += __shfl_xor(ssq, 16, 64);
-    ssq += __shfl_xor(ssq, 32, 64);
+    const float ssq = sum4(q2[0] + q2[1]);
     const int cslice = (n0 >> 6) + wn;
     if (q4 == 0 && (FULL || (m < g.M && cslice * 64 < g.N)))
       *reinterpret_cast<float2*>(g.spart + ((size_t)m * (g.N >> 6) + cslice) * 2) = make_float2(smean, ssq);
