@@ -73,9 +73,16 @@ __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], co
     } else if (epi_has_bias(EPI)) {
       v += PRE ? ec.bias[ni] : *reinterpret_cast<const f32x4*>(lbias + (FULL || n < g.N ? n : 0));
     }
-    if (EPI == GE_GELU || EPI == GE_GELU_LN) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+    if (EPI == GE_GELU || EPI == GE_GELU_LN) {   // quick_gelu_f on 4 values with the multiplies / adds packed
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 kk = {-2.4554669595930157f, -2.4554669595930157f}, one = {1.f, 1.f};
+      const f2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+      const f2 tl = lo * kk, th = hi * kk;
+      const f2 dl = f2{__builtin_amdgcn_exp2f(tl[0]), __builtin_amdgcn_exp2f(tl[1])} + one;
+      const f2 dh = f2{__builtin_amdgcn_exp2f(th[0]), __builtin_amdgcn_exp2f(th[1])} + one;
+      const f2 rl = lo * f2{__builtin_amdgcn_rcpf(dl[0]), __builtin_amdgcn_rcpf(dl[1])};
+      const f2 rh = hi * f2{__builtin_amdgcn_rcpf(dh[0]), __builtin_amdgcn_rcpf(dh[1])};
+      v = f32x4{rl[0], rl[1], rh[0], rh[1]};
     }
     const size_t o = orow * g.N + n;
     if (EPI == GE_PATCH && ok) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
