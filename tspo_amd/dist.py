@@ -65,12 +65,12 @@ def allreduce_mean_(bucket: torch.Tensor, n: int, group=None) -> torch.Tensor:
     return bucket
 
 
-METRIC_KEYS = ("ts_length", "completion_length", "reward", "advantages", "reward_mean", "reward_std")
+METRIC_KEYS = ("ts_length", "completion_length", "reward", "advantages", "reward_mean", "reward_std", "loss")
 
 
 def pack_metrics(values: Dict[str, float], rewards_per_func: Sequence[float]) -> torch.Tensor:
     """One small vector for every metric the reference gathers (tspo_trainer.py:610-634)."""
-    return torch.tensor([float(values[k]) for k in METRIC_KEYS] + [float(x) for x in rewards_per_func] + [1.0],
+    return torch.tensor([float(values.get(k, 0.0)) for k in METRIC_KEYS] + [float(x) for x in rewards_per_func] + [1.0],
                         dtype=torch.float64)
 
 

@@ -70,7 +70,8 @@ class SyntheticFeatures:
     """Seeded stand-in for the feature cache: unit-normal frame features in which the frames of a planted segment are
     pulled towards the text feature, so the clip score and the relevance mask carry signal."""
 
-    def __init__(self, T=512, D=768, seed=0, device="cuda"):
+    def __init__(self, T=512, D=768, seed=0, device="cuda", signal=0.75):
+        self.signal = float(signal)   # how strongly the relevant frames point at the text (0.75: found at once; ~0.1: noisy rewards)
         self.T, self.D, self.seed, self.dev = T, D, seed, torch.device(device)
 
     def batches(self, rank: int, world: int, bs: int) -> Iterator[Batch]:
@@ -82,7 +83,7 @@ class SyntheticFeatures:
             start = torch.randint(0, self.T - self.T // 8, (bs,), generator=g, device=self.dev)
             pos = torch.arange(self.T, device=self.dev)[None]
             mask = (pos >= start[:, None]) & (pos < start[:, None] + self.T // 8)
-            f = f + 0.75 * mask[..., None] * t
+            f = f + self.signal * mask[..., None] * t
             yield Batch(f, t, ops.clip_scores(t, f), mask, "specific" if i % 4 else "general")
             i += 1
 
@@ -177,7 +178,6 @@ def train(cfg: TrainConfig, data, reward_model: Callable[[torch.Tensor, Batch], 
         tau = annealed_tau(cfg.score_tau, step, cfg.max_steps)
         acc_m: Dict[str, float] = {k: 0.0 for k in tdist.METRIC_KEYS}
         acc_r = [0.0] * len(REWARD_NAMES)
-        loss_v = 0.0
         for _micro in range(cfg.gradient_accumulation_steps):
             b = next(it)
             k = rewards.training_sample_len(cfg.training_sample_len, b.item_type)
@@ -194,11 +194,11 @@ def train(cfg: TrainConfig, data, reward_model: Callable[[torch.Tensor, Batch], 
             acc_m["reward_std"] += w * rew.std(dim=1).mean().item()
             for j in range(len(REWARD_NAMES)):
                 acc_r[j] += w * rpf[..., j].mean().item()
-            loss_v += w * st["loss"].mean().item()
+            acc_m["loss"] += w * st["loss"].mean().item()
         ost = trainer.optimizer_step()
         if (step + 1) % cfg.logging_steps == 0:
             m = tdist.reduce_metrics(tdist.pack_metrics(acc_m, acc_r), len(REWARD_NAMES), REWARD_NAMES)
-            m.update(step=step + 1, loss=loss_v, learning_rate=ost["lr"], score_tau=tau,
+            m.update(step=step + 1, learning_rate=ost["lr"], score_tau=tau,
                      grad_norm=float(ost["grad_norm_scale"][0]) / ost["world"], elapsed_s=round(time.perf_counter() - t0, 3))
             last_metrics = m
             if logf:
