@@ -180,11 +180,12 @@ def test_training_driver_accumulation_logging_checkpoint_resume(tmp_path):
     from tspo_amd import train as tt
     kw = dict(max_steps=6, num_generations=4, training_sample_len=8, gradient_accumulation_steps=2, save_steps=2,
               save_total_limit=2, dim=64, heads=8, seed=11)
-    data = lambda: tt.SyntheticFeatures(T=96, D=64, seed=11, device=DEV)
+    data = lambda: tt.SyntheticFeatures(T=96, D=64, seed=11, device=DEV, signal=0.1)   # weak signal: rewards differ, gradients flow
     cfg_a = tt.TrainConfig(output_dir=str(tmp_path / "a"), **kw)
     ma = tt.train(cfg_a, data(), resume=False)
     lines = [json.loads(l) for l in open(os.path.join(cfg_a.output_dir, "metrics.jsonl"))]
     assert [l["step"] for l in lines] == [1, 2, 3, 4, 5, 6]
+    assert max(l["grad_norm"] for l in lines) > 0 and max(l["reward_std"] for l in lines) > 0   # the run actually learns something
     assert abs(lines[0]["learning_rate"] - 5e-4) < 1e-12 and abs(lines[3]["learning_rate"] - 5e-4 * 3 / 6) < 1e-12   # linear decay
     assert abs(lines[2]["score_tau"] - (0.025 - (0.025 - 0.01) / 6 * 2)) < 1e-12                                    # tau annealing
     for key in ("reward", "reward_std", "advantages", "ts_length", "rewards/accuracy_reward",
