@@ -354,6 +354,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()   # rank 0 is still profiling / printing while the others are done: leave together
         dist.destroy_process_group()
 
 
