@@ -261,10 +261,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     sfor<0, 8>([&](auto nn_) {
       constexpr int nn = decltype(nn_)::value;
       constexpr int slot = nn == 7 ? 7 + PAR : nn;
-      if (nn == 2) read_a(nbuf, nkk, na);
       sfor<0, 8>([&](auto mi_) {
         constexpr int mi = decltype(mi_)::value;
-        if (nn >= 2 && (nn * 8 + mi - 16) % 6 == 0) piece(std::integral_constant<int, (nn * 8 + mi - 16) / 6>{});
+        // the next K-half's A fragments: one read per column tile (fragment 7 rides with tile 3), so that every column
+        // tile carries the same four memory instructions - A read, staging write, staging reload, W refill
+        if (nn < 7 && mi == 1) na[nn] = *reinterpret_cast<const i32x4*>(nbuf + fbaseA + nn * 2048 + wco);
+        if (nn == 3 && mi == 5) na[7] = *reinterpret_cast<const i32x4*>(nbuf + fbaseA + 7 * 2048 + wco);
+        if (mi == 3) piece(nn_, std::integral_constant<int, 0>{});   // ds_write of staging piece nn ...
+        if (mi == 6) piece(nn_, std::integral_constant<int, 1>{});   // ... and its reload, half a column tile later
         const i32x4 wf = fw[slot], af = fa[mi];
         if (ZERO) A4_MFMA_Z(nn, mi, wf, af); else A4_MFMA(nn, mi, wf, af);
       });
@@ -280,12 +284,16 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     const char* cur = lds + cb * G3_STAGE;
     const char* nxt = lds + nb * G3_STAGE;
     // [A]: K-half 0; fragments of K-half 1 of this stage; W pieces: S_j(it+1) -> buffer nb, then G_j(it+2)
-    khalf(zero_, std::integral_constant<int, 0>{}, fa0, fa1, cur, 1, [&](auto j_) { swrite_w(j_, nb); gload_w(j_); });
+    khalf(zero_, std::integral_constant<int, 0>{}, fa0, fa1, cur, 1, [&](auto j_, auto ph_) {
+      if (decltype(ph_)::value == 0) swrite_w(j_, nb); else gload_w(j_);
+    });
     adv_w();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage it+1 complete in LDS; buffer cb fully read
     __builtin_amdgcn_s_waitcnt(0xC07F);   // (the same wait as a builtin: free at run time, keeps hipcc's wait model exact)
     // [B]: K-half 1; fragments of K-half 0 of stage it+1; A pieces of set `sa`: S_j(it+2) -> buffer cb, then G_j(it+4)
-    khalf(std::false_type{}, std::integral_constant<int, 1>{}, fa1, fa0, nxt, 0, [&](auto j_) { swrite_a(j_, sa, cb); gload_a(j_, sa); });
+    khalf(std::false_type{}, std::integral_constant<int, 1>{}, fa1, fa0, nxt, 0, [&](auto j_, auto ph_) {
+      if (decltype(ph_)::value == 0) swrite_a(j_, sa, cb); else gload_a(j_, sa);
+    });
     adv_a();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     ++it;
