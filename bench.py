@@ -150,7 +150,7 @@ def cpu_baseline(T, k):
 
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
-POLICY_STEP_LAUNCHES = 17       # profiles/r2_d_kernel_trace_policy_step_fp32.txt: 7 rollout + 8 backward + 2 optimizer
+POLICY_STEP_LAUNCHES = 16       # profiles/r2_f_kernel_trace_policy_step_fp32.txt: 7 rollout + 7 backward + 2 optimizer
 
 
 def policy_step_roofline(B: int, T: int, D: int, step_s: float) -> dict:

@@ -174,6 +174,19 @@ int tspo_selector_backward_ex(const tspo_selector_weights* w, const float* img, 
                               const tspo_selector_grads* grads,
                               void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags);
 
+/* tspo_grpo_pg_grad + tspo_selector_backward_ex in one call with one launch
+ * less: the kernel that turns dscores into dL/dh derives dscores itself from
+ * (rewards [B,G], logp [B,T], idx [B,G,k] ascending) - same arithmetic and
+ * order as tspo_grpo_pg_grad: adv / loss are bit-identical to the two-call
+ * form, gradients agree to rounding (< 1e-6 of their maximum).  G <= 64.  `scale` multiplies dL/dscores (e.g. 1/(B*accum)).
+ * Replaces loss.backward() of tspo_trainer.py:587-609 end to end.           */
+int tspo_policy_backward(const tspo_selector_weights* w, const float* img, const float* txt,
+                         const float* rewards, const float* logp, const int64_t* idx,
+                         int B, int T, int D, int H, int M, int window, float tau,
+                         int G, int k, float adv_eps, float scale,
+                         const tspo_selector_grads* grads, float* adv, float* loss,
+                         void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags);
+
 /* ------------------------------------------------------------------------
  * Optimiser on the flat parameter bucket
  * ------------------------------------------------------------------------ */

@@ -302,6 +302,20 @@ def test_fused_policy_entries_match_the_separate_ones():
         np.testing.assert_allclose(pb.cpu().numpy(), pa.cpu().numpy(), rtol=1e-5, atol=1e-8)
         np.testing.assert_allclose(mb.cpu().numpy(), ma.cpu().numpy(), rtol=1e-5, atol=1e-10)
         np.testing.assert_allclose(vb.cpu().numpy(), va.cpu().numpy(), rtol=1e-5, atol=1e-13)
+    # tspo_policy_backward == tspo_grpo_pg_grad + tspo_selector_backward (advantages / loss bit for bit, gradients to rounding)
+    Bp, Tp, Dp, Hp, Wp, taup, Gp, kp = 2, 300, 768, 8, 12, 0.025, 8, 16
+    img, txt = G_(synth.normal((Bp, Tp, Dp), 91)), G_(synth.normal((Bp, 1, Dp), 92))
+    flat = flat_from_state(synth.selector_state(Dp, seed=93, std=0.5 / np.sqrt(Dp), bias_std=0.05), Dp)
+    sc, _, ws = ops.selector_forward(flat, img, txt, ops.clip_scores(txt, img), Hp, Wp, taup, want_attn=False)
+    ro = ops.gumbel_topk(sc, kp, Gp, seed=7)
+    rw = G_(synth.uniform((Bp, Gp), 94).reshape(Bp, Gp).astype(np.float32))
+    ga, gb = torch.zeros_like(flat), torch.zeros_like(flat)
+    adv_a, dl_a, loss_a = ops.grpo_pg_grad(rw, ro["logp"], ro["idx"], scale=0.5)
+    ops.selector_backward(flat, ga, img, txt, dl_a, Hp, Wp, taup, ws)
+    adv_b, loss_b = ops.policy_backward(flat, gb, img, txt, rw, ro["logp"], ro["idx"], Hp, Wp, taup, ws, scale=0.5)
+    assert torch.equal(adv_a, adv_b) and torch.equal(loss_a, loss_b)
+    gmax = ga.abs().max().item()
+    assert gmax > 0 and (ga - gb).abs().max().item() <= 2e-6 * gmax     # dL/dscores differs in the last bit (measured 8e-7)
     # ragged tail (n % 4 != 0) of the vectorised kernels
     n = 1003
     g = G_(synth.normal((n,), 90, 1e-2))

@@ -61,6 +61,8 @@ SIGNATURES = {
     "tspo_selector_forward_ex": (_i, [C.POINTER(SelectorWeights), _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _sz, _p, _i]),
     "tspo_selector_backward_ex": (_i, [C.POINTER(SelectorWeights), _p, _p, _p, _i, _i, _i, _i, _i, _i, _f,
                                        C.POINTER(SelectorGrads), _p, _sz, _p, _i]),
+    "tspo_policy_backward": (_i, [C.POINTER(SelectorWeights), _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f,
+                                  C.POINTER(SelectorGrads), _p, _p, _p, _sz, _p, _i]),
     "tspo_grad_norm_scale": (_i, [_p, _sz, _f, _f, _p, _p, _sz, _p]),
     "tspo_adamw_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _p, _p]),
     "tspo_adamw_clip_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _f, _p, _p, _sz, _p]),

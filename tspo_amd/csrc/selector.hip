@@ -847,11 +847,20 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict_
 // dh_t = (ds_t / tau / M) * sum_m [ e_m/den_m - (h.e_m) |e_m| / (den_m^2 |h|) h ]
 // The launch also carries the two weight transposes the data-gradient GEMMs need (W1^T, W2^T; blocks past n_score, 32x32
 // tiles): they are independent of the score gradient and far too small for a launch of their own.
+// PG (tspo_policy_backward): dscores is not an input - the wave of row (b, t) derives it from the rollouts
+// (tspo_trainer.py:587-609: group-relative advantage of the G rewards of prompt b, then the closed-form policy-gradient
+// term of tspo_pg_grad_logits) with the same arithmetic, in the same order, as grpo_pg_grad_kernel.
+struct PgIn {
+  const float* rewards; const float* logp; const int64_t* idx;   // [B,G], [B,T], [B,G,k] ascending
+  int G, k; float eps, scale;
+  float* adv; float* loss;                                       // out: [B,G], [B] (nullable)
+};
+template <bool PG>
 __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict__ h, const float* __restrict__ txt,
                                                         const float* __restrict__ dscores, float* __restrict__ dh,
                                                         int B, int T, int D, int M, float tau, int n_score,
                                                         const float* __restrict__ w1, float* __restrict__ w1t,
-                                                        const float* __restrict__ w2, float* __restrict__ w2t) {
+                                                        const float* __restrict__ w2, float* __restrict__ w2t, PgIn pg) {
   if ((int)blockIdx.x >= n_score) {
     __shared__ float tile[32][33];
     const int tpr = (D + 31) / 32;
@@ -877,7 +886,44 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
   float hh = 0.f;
   for (int d = lane; d < D; d += 64) hh += hr[d] * hr[d];
   const float hn = sqrtf(wave_sum(hh));
-  const float g = dscores[row] / tau / (float)M;
+  float ds;
+  if (PG) {   // G <= 64: lane g owns rollout g of this row's prompt
+    const int t = (int)(row - (long)b * T), G = pg.G, k = pg.k;
+    const bool live = lane < G;
+    const float r = live ? pg.rewards[(size_t)b * G + lane] : 0.f;
+    const float mean = wave_sum(r) / (float)G;
+    const float dm = live ? r - mean : 0.f;
+    const float sd = sqrtf(wave_sum(dm * dm) / (float)(G - 1));
+    const float a = live ? (r - mean) / (sd + pg.eps) : 0.f;
+    bool hit = false;
+    if (live) {
+      const int64_t* my = pg.idx + ((size_t)b * G + lane) * k;
+      int lo = 0, hi = k - 1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int v = (int)my[mid];
+        if (v == t) { hit = true; break; }
+        if (v < t) lo = mid + 1; else hi = mid - 1;
+      }
+    }
+    const float p = expf(pg.logp[row]);
+    const float invk = 1.f / (float)k, invG = 1.f / (float)G;
+    const float y = (hit ? invk : 0.f) - p;
+    float acc = 0.f, sumA = 0.f;
+    for (int gg = 0; gg < G; ++gg) {   // serial over the rollouts, like the stand-alone kernel (same bits, same fma)
+      const float ag = __shfl(a, gg, 64);
+      acc += ag * __shfl(y, gg, 64);
+      sumA += ag;
+    }
+    ds = -invG * acc * pg.scale;
+    if (t == 0) {
+      if (live) pg.adv[(size_t)b * G + lane] = a;
+      if (lane == 0 && pg.loss) pg.loss[b] = -sumA * invG;
+    }
+  } else {
+    ds = dscores[row];
+  }
+  const float g = ds / tau / (float)M;
   for (int d = lane; d < D; d += 64) dh[row * D + d] = 0.f;
   for (int m = 0; m < M; ++m) {
     const float* er = txt + ((size_t)b * M + m) * D;
@@ -1405,10 +1451,10 @@ int dgrad_with_wgrad(const float* dY, const float* Wt, const float* R, float* dX
 static int selector_backward_impl(const tspo_selector_weights* w, const float* img, const float* txt,
                                   const float* dscores, int B, int T, int D, int H, int M, int window, float tau,
                                   const tspo_selector_grads* g, void* workspace, size_t workspace_bytes,
-                                  tspo_stream_t stream, int flags) {
+                                  tspo_stream_t stream, int flags, const PgIn* pg = nullptr) {
   const bool split = (flags & TSPO_SEL_BF16X3) != 0;
   TSPO_REQUIRE((flags & ~TSPO_SEL_BF16X3) == 0, "selector_backward: unknown flags 0x%x", flags);
-  TSPO_REQUIRE(w && img && txt && dscores && g && workspace, "selector_backward: null pointer");
+  TSPO_REQUIRE(w && img && txt && (dscores || pg) && g && workspace, "selector_backward: null pointer");
   TSPO_REQUIRE(g->wqkv && g->bqkv && g->w1 && g->b1 && g->w2 && g->b2, "selector_backward: null grad pointer");
   if (int e = check_dims("selector_backward", B, T, D, H, M, window)) return e;
   SelWs s = carve(workspace, B, T, D, H, M, window);
@@ -1422,8 +1468,12 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
   float* part_qkv = s.part + (size_t)s.S * 2 * DD;
   // score -> dh2
   const int n_score = (BT + 3) / 4, tpr = (D + 31) / 32;
-  hipLaunchKernelGGL(score_bwd_kernel, dim3(n_score + 2 * tpr * tpr), dim3(256), 0, st, s.h2, txt, dscores, s.dh2, B, T, D, M,
-                     tau, n_score, w->w1, s.w1t, w->w2, s.w2t);
+  if (pg)
+    hipLaunchKernelGGL(score_bwd_kernel<true>, dim3(n_score + 2 * tpr * tpr), dim3(256), 0, st, s.h2, txt, nullptr, s.dh2, B, T,
+                       D, M, tau, n_score, w->w1, s.w1t, w->w2, s.w2t, *pg);
+  else
+    hipLaunchKernelGGL(score_bwd_kernel<false>, dim3(n_score + 2 * tpr * tpr), dim3(256), 0, st, s.h2, txt, dscores, s.dh2, B,
+                       T, D, M, tau, n_score, w->w1, s.w1t, w->w2, s.w2t, PgIn{});
   // exact-fp32 path with 128-divisible D: bias-gradient column sums come out of the weight-gradient kernels, and each of
   // the two DxD weight gradients shares a launch with the data-gradient GEMM that does not depend on it
   const bool fused = !split && D % 128 == 0 && D % 96 == 0;
@@ -1483,6 +1533,18 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L);
   (void)img;
   return tspo::check_launch("selector_backward");
+}
+
+extern "C" int tspo_policy_backward(const tspo_selector_weights* w, const float* img, const float* txt, const float* rewards,
+                                    const float* logp, const int64_t* idx, int B, int T, int D, int H, int M, int window,
+                                    float tau, int G, int k, float adv_eps, float scale, const tspo_selector_grads* grads,
+                                    float* adv, float* loss, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
+                                    int flags) {
+  TSPO_REQUIRE(rewards && logp && idx && adv, "policy_backward: null pointer");
+  TSPO_REQUIRE(G >= 1 && G <= 64 && k >= 1 && k <= T, "policy_backward: bad dims G=%d (1..64) k=%d T=%d", G, k, T);
+  const PgIn pg{rewards, logp, idx, G, k, adv_eps, scale, adv, loss};
+  return selector_backward_impl(w, img, txt, nullptr, B, T, D, H, M, window, tau, grads, workspace, workspace_bytes, stream,
+                                flags, &pg);
 }
 
 extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const float* img, const float* txt,

@@ -227,6 +227,28 @@ def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dsc
           "tspo_selector_backward")
 
 
+def policy_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, rewards, logp, idx, H, window, tau, ws,
+                    scale: float = 1.0, eps: float = 1e-4, precision: str = "fp32"):
+    """grpo_pg_grad + selector_backward with one launch less (the score-gradient kernel derives dL/dscores from the
+    rollouts itself): -> (adv [B,G], loss [B]); gradients go to `flat_grad` (equal to the two-call form to rounding)."""
+    _need_gpu(flat, flat_grad, img, txt, rewards, logp, idx, ws)
+    x, e, r, lp = _f32c(img), _f32c(txt), _f32c(rewards), _f32c(logp)
+    ix = idx.to(torch.int64).contiguous()
+    B, T, D = x.shape
+    M = e.shape[1]
+    _, G, k = ix.shape
+    if tuple(r.shape) != (B, G) or tuple(lp.shape) != (B, T):
+        raise ValueError(f"rewards {tuple(r.shape)} / logp {tuple(lp.shape)} do not match idx {tuple(ix.shape)}, feats {tuple(x.shape)}")
+    w = _sel_structs(flat, D, _lib.SelectorWeights)
+    g = _sel_structs(flat_grad, D, _lib.SelectorGrads)
+    adv = torch.empty_like(r)
+    loss = torch.empty((B,), dtype=torch.float32, device=x.device)
+    check(_lib.lib().tspo_policy_backward(C.byref(w), _ptr(x), _ptr(e), _ptr(r), _ptr(lp), _ptr(ix), B, T, D, H, M, int(window),
+                                          float(tau), G, k, float(eps), float(scale), C.byref(g), _ptr(adv), _ptr(loss), _ptr(ws),
+                                          ws.numel(), _stream(), _sel_flags(precision)), "tspo_policy_backward")
+    return adv, loss
+
+
 def grad_norm_scale(grad: torch.Tensor, n: int, pre_scale: float = 1.0, max_norm: float = 1.0,
                     out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> device tensor [2] = (||g||, clip coefficient * pre_scale); no host sync.  `out` / `ws` (>= 2048 bytes) let a

@@ -171,15 +171,20 @@ class PolicyTrainer:
         if self._micro >= self.grad_accum_steps:
             raise RuntimeError("gradient accumulation boundary reached: call optimizer_step() before another backward()")
         B = feats.shape[0]
-        adv, dlog, loss = ops.grpo_pg_grad(rewards, logp, idx, scale=1.0 / (B * self.grad_accum_steps))
         if self._micro == 0:
             target = self.grad
         else:
             if self._gmicro is None:
                 self._gmicro = torch.empty_like(self.grad)
             target = self._gmicro
-        ops.selector_backward(self.flat, target, feats, txt, dlog, self.heads, self.window, ctx.tau, ctx.ws,
-                              precision=self.gemm_precision)
+        scale = 1.0 / (B * self.grad_accum_steps)
+        if idx.shape[1] <= 64:      # advantage -> dL/dscores inside the backward's first kernel (one launch less)
+            adv, loss = ops.policy_backward(self.flat, target, feats, txt, rewards, logp, idx, self.heads, self.window, ctx.tau,
+                                            ctx.ws, scale=scale, precision=self.gemm_precision)
+        else:
+            adv, dlog, loss = ops.grpo_pg_grad(rewards, logp, idx, scale=scale)
+            ops.selector_backward(self.flat, target, feats, txt, dlog, self.heads, self.window, ctx.tau, ctx.ws,
+                                  precision=self.gemm_precision)
         if target is not self.grad:
             self.grad[: self.n_train].add_(target[: self.n_train])
         self._micro += 1
