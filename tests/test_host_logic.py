@@ -228,3 +228,17 @@ def test_frame_idx_join_and_pickle(tmp_path):
     anno2 = [{"id": 17}, {"id": 18}]
     assert tio.write_frame_idx_json(anno2, tio.load_results_pickle(str(pk)), str(tmp_path / "l.json"), dataset="LongVideoBench") == 1
     assert tio.FrameIdGenerator.problem_of("<image>\nQuestion: what happens?\nOptions:\nA. x") == "what happens?"
+
+
+def test_bench_accounting_helpers():
+    """The FLOP / byte accounting bench.py divides by: 162.03 GFLOP per CLIP-L/14 frame, of which 155.53 are
+    GEMM FLOPs; algorithmic GEMM bytes per launch; the policy-step roofline block."""
+    import bench
+    c = bench.CLIP_L14
+    g, a = bench.gemm_flops_per_frame(c), bench.attn_flops_per_frame(c)
+    assert abs(g / 1e9 - 155.53) < 0.01 and abs(a / 1e9 - 6.49) < 0.01 and abs((g + a) / 1e9 - 162.03) < 0.02
+    assert abs(bench.alg_bytes_per_launch(c, 1024) / 1e9 - 2.39) < 0.01
+    r = bench.policy_step_roofline(4, 512, 768, 4e-4)
+    assert r["bound"] == "mfma" and r["dtype"] == "f32" and r["launches_per_step"] == bench.POLICY_STEP_LAUNCHES
+    assert abs(r["gemm_flop_per_step"] / 1e9 - 28.99) < 0.01
+    assert abs(r["achieved"] - 28.99e9 / 4e-4 / 1e12) < 0.1 and abs(r["frac"] - r["achieved"] / 157.3) < 1e-3
