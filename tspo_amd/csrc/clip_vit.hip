@@ -92,9 +92,12 @@ template <> __device__ __forceinline__ float load_pixel<uint8_t>(const uint8_t* 
   return ((float)p[i] / 255.0f - mean) / sd;
 }
 
-template <typename TP>
+// IMAGE / PATCH / KP > 0: compile-time geometry (CLIP-L/14: 224 / 14 / 640) - every index division below is by a runtime
+// value otherwise, ~30 instructions each, five per element
+template <typename TP, int IMAGE = 0, int PATCH = 0, int KP = 0>
 __global__ __launch_bounds__(256) void patch_gather_kernel(const TP* __restrict__ px, bf16_t* __restrict__ out,
-                                                           int n_frames, int image, int patch, int Kp) {
+                                                           int n_frames, int image_rt, int patch_rt, int Kp_rt) {
+  const int image = IMAGE ? IMAGE : image_rt, patch = PATCH ? PATCH : patch_rt, Kp = KP ? KP : Kp_rt;
   const int gw = image / patch, P = gw * gw, pp = patch * patch, Kreal = 3 * pp;
   const int oct = Kp / 8;
   const size_t total = (size_t)n_frames * P * oct;
@@ -1325,7 +1328,12 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       case TSPO_F32: hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
       case TSPO_BF16: hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
       case TSPO_F16: hipLaunchKernelGGL(patch_gather_kernel<_Float16>, dim3(nb), dim3(256), 0, st, (const _Float16*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
-      case TSPO_U8: hipLaunchKernelGGL(patch_gather_kernel<uint8_t>, dim3(nb), dim3(256), 0, st, (const uint8_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
+      case TSPO_U8:
+        if (c.image == 224 && c.patch == 14 && Kp == 640)
+          hipLaunchKernelGGL((patch_gather_kernel<uint8_t, 224, 14, 640>), dim3(nb), dim3(256), 0, st, (const uint8_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp);
+        else
+          hipLaunchKernelGGL(patch_gather_kernel<uint8_t>, dim3(nb), dim3(256), 0, st, (const uint8_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp);
+        break;
       default: return tspo::set_err(TSPO_EINVAL, "clip_vit_forward: bad pixel_dtype %d", pixel_dtype);
     }
     unsigned cb = (unsigned)(((size_t)n_frames * C + 255) / 256);
