@@ -2,6 +2,7 @@
 """bench.py - frames scored/s (+ rollouts/s) of the TSPO temporal-sampling hot path on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                      # no launcher: spawns its own 8 ranks (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -150,10 +151,34 @@ def cpu_baseline(T, k):
 
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
-POLICY_STEP_LAUNCHES = 16       # profiles/r2_f_kernel_trace_policy_step_fp32.txt: 7 rollout + 7 backward + 2 optimizer
 
 
-def policy_step_roofline(B: int, T: int, D: int, step_s: float) -> dict:
+def count_kernel_launches(fn, reps: int = 3):
+    """Kernel launches of one call of `fn`, counted LIVE by the profiler's device-activity records (roctracer) over
+    `reps` calls; returns (launches per call, {kernel name: launches per call}) or (None, reason) if tracing is
+    unavailable in this process."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        fn()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+        names = {}
+        for ev in prof.events():
+            if str(getattr(ev, "device_type", "")).endswith("CUDA") and ev.name and not ev.name.lower().startswith(("memcpy", "memset")):
+                short = ev.name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].split("::")[-1]
+                names[short] = names.get(short, 0) + 1
+        total = sum(names.values())
+        if total == 0 or total % reps:
+            return None, f"profiler saw {total} device kernels over {reps} calls"
+        return total // reps, {k: v / reps for k, v in sorted(names.items())}
+    except Exception as e:      # tracing unavailable (e.g. under rocprofv3): report why, never a made-up constant
+        return None, f"{type(e).__name__}: {e}"
+
+
+def policy_step_roofline(B: int, T: int, D: int, step_s: float, launches=None, per_kernel=None) -> dict:
     """What bounds one policy step (selector forward + G rollouts + backward + clip + AdamW): its fp32 MFMA GEMMs.
     Forward: q|k|v [BT,D]x[D,3D] + two [BT,D]x[D,D]; backward: two data gradients [BT,D]x[D,D] and the three weight
     gradients (D*D, D*D, 3*D*D outputs over BT rows).  Everything else (banded attention, scores, Gumbel top-k, advantage,
@@ -164,8 +189,68 @@ def policy_step_roofline(B: int, T: int, D: int, step_s: float) -> dict:
     ach = (fwd + bwd) / step_s / 1e12
     return {"bound": "mfma", "unit": "TFLOP/s", "dtype": "f32", "gemm_flop_per_step": fwd + bwd,
             "achieved": round(ach, 1), "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-            "launches_per_step": POLICY_STEP_LAUNCHES, "us_per_step": round(step_s * 1e6, 1),
+            "launches_per_step": launches, "launches_source": "counted live (torch.profiler device records)" if launches else per_kernel,
+            "launches_by_kernel": per_kernel if launches else None, "us_per_step": round(step_s * 1e6, 1),
             "note": "achieved = GEMM FLOPs / WHOLE step time (the non-GEMM launches are inside the denominator)"}
+
+
+def comm_probe(backend: str, world: int, dev, n_bucket: int) -> dict:
+    """{"backend", "world", "allreduce_us", ...}: the gradient-bucket all-reduce (11.8 MB fp32, tspo_amd.dist.
+    allreduce_bucket_, the one collective of a data-parallel TSPO step) timed on this job's process group.  At N=1 a
+    one-rank group is created for the probe and destroyed again, so librccl / the device binding are exercised on every
+    run while the timed regions below stay collective-free.  Never fatal: a failure is reported in the line."""
+    import datetime
+    import torch.distributed as dist
+    from tspo_amd import dist as tdist
+    info = {"backend": backend, "library": "rccl" if backend == "nccl" else backend, "world": world,
+            "bucket_bytes": 4 * n_bucket, "allreduce_us": None}
+    own = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ["MASTER_PORT"] = str(tdist.free_port())
+            kw = {"device_id": dev} if backend == "nccl" else {}
+            dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), **kw)
+            own = True
+        info["world"] = dist.get_world_size()
+        bucket = torch.ones(n_bucket + 8, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            tdist.allreduce_bucket_(bucket, n_bucket)
+        torch.cuda.synchronize()
+        if dist.get_world_size() > 1:
+            dist.barrier()
+        bucket.fill_(1.0)
+        reps = 4          # 1 -> world^4 stays exact in fp32 for any world size
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tdist.allreduce_bucket_(bucket, n_bucket)
+        torch.cuda.synchronize()
+        ok = bool((bucket[:n_bucket] == float(info["world"]) ** reps).all()) and bool((bucket[n_bucket:] == 1.0).all())
+        reps = 20
+        bucket.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tdist.allreduce_bucket_(bucket, n_bucket)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / reps * 1e6
+        t = torch.tensor([us], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if dist.get_world_size() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        info.update(allreduce_us=round(t.item(), 1), sum_correct=ok,
+                    algbw_GBps=round(4 * n_bucket / (t.item() * 1e-6) / 1e9, 2))
+        if backend == "nccl":
+            try:
+                info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
+    except Exception as e:
+        info["error"] = f"{type(e).__name__}: {e}"[:300]
+    finally:
+        if own and dist.is_initialized():
+            dist.destroy_process_group()
+    return info
 
 
 def main():
@@ -186,28 +271,38 @@ def main():
     ap.add_argument("--rollout-cfg", default="4,512,8,16", help="B,T,G,k of the policy step (configs[2]: 4,512,8,16; configs[4] stress: 1,4096,16,16)")
     ap.add_argument("--no-pruned", action="store_true", help="skip the extra (non-headline) run with the pruned last block")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: stand-alone LayerNorm passes instead of folding them into the GEMMs")
+    ap.add_argument("--no-comm-probe", action="store_true", help="skip the RCCL probe (init + timed all-reduce of the gradient bucket)")
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU path in the product); use gpurun")
+    from tspo_amd import dist as tdist
+    if a.gpus > 1 and not tdist.launched_by_torchrun():
+        # bare `python bench.py --gpus N`: become the launcher - one rank per GPU, like torch.distributed.run would
+        if not a.same_device and torch.cuda.device_count() < a.gpus:
+            sys.exit(f"--gpus {a.gpus} but only {torch.cuda.device_count()} GPU(s) visible (use --same-device --backend gloo for a dry run)")
+        sys.exit(tdist.self_spawn(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        # the launcher's WORLD_SIZE is what actually runs; say so instead of dying (the JSON line reports n_gpus = world)
+        print(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
     if a.same_device:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
-        else:
-            dist.init_process_group(a.backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+        tdist.init_from_env(a.backend, device=dev)              # "nccl" = RCCL over xGMI
 
     from tspo_amd import ops
     from tspo_amd.pipeline import FrameScorer, PolicyTrainer
+
+    # ---- comm probe: how many ranks the collective library sees and what THE all-reduce of the step costs ----------
+    comm = None
+    if not a.no_comm_probe:
+        comm = comm_probe(a.backend, world, dev, ops.trainable_numel(768))
 
     c = CLIP_L14
     B, T, k = a.videos, a.frames, a.topk
@@ -287,6 +382,8 @@ def main():
         trainer = PolicyTrainer(flat.clone())
         rsec = timed(lambda: trainer.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 200), 3)
         rollouts = Bt * G * world * max(a.steps, 200) / rsec
+        n_launch, by_kernel = (None, "counted on rank 0 only") if (rank or world > 1) else count_kernel_launches(
+            lambda: trainer.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau))
         # opt-in split-precision selector GEMMs (NOT the headline number): see DESIGN.md, TSPO_SEL_BF16X3
         trainer_x3 = PolicyTrainer(flat.clone(), gemm_precision="bf16x3")
         xsec = timed(lambda: trainer_x3.step(feats, ttxt, clip, lambda idx: rew, G, kt, tau), max(a.steps, 200), 3)
@@ -343,14 +440,16 @@ def main():
                         "(~1e-5 relative error vs exact fp32); not used for `rollouts_per_s`"},
             "rollouts_config": None if rollouts is None else {"workload": "policy step (reward LLM excluded); default = configs[2]",
                                                               "B": Bt, "T": Tt, "G": G, "k": kt},
-            "rollouts_roofline": None if rollouts is None else policy_step_roofline(Bt, Tt, 768, Bt * G * world / rollouts),
+            "rollouts_roofline": None if rollouts is None else policy_step_roofline(Bt, Tt, 768, Bt * G * world / rollouts, n_launch, by_kernel),
             "encode_tflops": round((gemm_flops_per_frame(c) + attn_flops_per_frame(c)) * fps / 1e12, 1),
             "optional_pruned_last_block": None if pruned_fps is None else {
                 "frames_scored_per_s": round(pruned_fps, 2),
                 "note": "opt-in ops.clip_vit_forward(prune_last_layer=True): last block for the class-token row only "
                         "(same features); not used for `value`"},
             "split_ms": {"encode": round(sec / a.steps * 1e3 - sel_sec * 1e3, 3), "score_select": round(sel_sec * 1e3, 3)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "comm": comm,
+            "launcher": "torch.distributed.run" if (world > 1 and not os.environ.get("TSPO_SELF_SPAWNED")) else
+                        ("self-spawn" if world > 1 else "single process"),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -193,7 +193,7 @@ int tspo_policy_backward(const tspo_selector_weights* w, const float* img, const
 
 /* sum of squares of a flat f32 buffer -> out[0] = ||g||_2, out[1] =
  * min(1, max_norm/(norm+1e-6)) * pre_scale  (torch clip_grad_norm_ coefficient;
- * HF Trainer max_grad_norm=1.0).  workspace >= 1024 floats.                 */
+ * HF Trainer max_grad_norm=1.0).  workspace >= 2048 bytes (512 floats).     */
 int tspo_grad_norm_scale(const float* grad, size_t n, float pre_scale, float max_norm, float* out2,
                          void* workspace, size_t workspace_bytes, tspo_stream_t stream);
 
@@ -208,8 +208,8 @@ int tspo_adamw_step(float* param, const float* grad, float* m, float* v, size_t 
  * (HF Trainer: clip_grad_norm_(max_grad_norm) then optimizer.step()): the
  * AdamW kernel finishes the norm reduction itself and applies
  * coefficient * pre_scale to the gradient on the fly (grad is not modified).
- * out2 f32 [2] = (||g||_2, applied scale); workspace >= 1024 floats;
- * buffers 16-byte aligned.                                                  */
+ * out2 f32 [2] = (||g||_2, applied scale); workspace >= 2048 bytes (512
+ * floats: one partial sum of squares per norm block); buffers 16-byte aligned. */
 int tspo_adamw_clip_step(float* param, const float* grad, float* m, float* v, size_t n,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float pre_scale, float max_norm, float* out2,

@@ -12,16 +12,75 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
-    """(rank, world, local_rank); initialises the default group when WORLD_SIZE > 1."""
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def init_from_env(backend: str = "nccl", device: "torch.device | None" = None, force: bool = False) -> Tuple[int, int, int]:
+    """(rank, world, local_rank); initialises the default group when WORLD_SIZE > 1 (or, with force=True, also for a
+    single rank: a world-size-1 "nccl" group still loads librccl and binds the device, so the collective calls below
+    really execute).  `device` binds the RCCL communicator to this rank's GPU."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port()) if world == 1 else "29500"
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def launched_by_torchrun() -> bool:
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def self_spawn(n: int, argv: Sequence[str], module: "str | None" = None, timeout: "float | None" = None) -> int:
+    """Start `n` ranks of this program on this node without torch.distributed.run (one process per GPU; what
+    `train_deepspeed.sh:14-16`'s `torchrun --nproc_per_node` does): `python <argv[0]> <argv[1:]>` (or `python -m module
+    <argv[1:]>`) n times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, a free rendezvous port and
+    the dmabuf IPC mode RCCL needs.  Children inherit stdout/stderr (rank 0 prints the result line).  Returns the first
+    non-zero exit code (the other ranks are terminated by PID as soon as one rank fails), else 0."""
+    import subprocess
+    import sys
+    import time
+    port = free_port()
+    cmd = [sys.executable] + (["-m", module] if module else [argv[0]]) + list(argv[1:])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSPO_SELF_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env))
+    t0, rc = time.monotonic(), 0
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0:
+                    rc = code
+        if timeout is not None and time.monotonic() - t0 > timeout:
+            rc = 124
+        if live and rc == 0:
+            time.sleep(0.05)
+    for p in live:                      # a rank failed (or timed out): stop exactly the processes started here
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
 
 
 def shard_prompts(n_global: int, world: int, rank: int) -> range:
@@ -42,11 +101,12 @@ def allreduce_bucket_(bucket: torch.Tensor, n: int, group=None, average: bool = 
     """THE gradient exchange of the data-parallel step: one in-place all-reduce(SUM) of bucket[:n] over the ranks of
     `group` ("nccl" = RCCL over xGMI on MI355X).  Returns the world size; with average=True the result is divided by it
     (PolicyTrainer keeps the sum and folds 1/world into the clip coefficient instead of a second pass over the bucket).
-    No-op (returns 1) when torch.distributed is not initialised."""
+    No-op (returns 1) when torch.distributed is not initialised.  bucket[:n] starts at the bucket's base address, so
+    the view RCCL sees keeps the allocation's alignment."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     world = dist.get_world_size(group)
-    if world > 1:
+    if world > 1 or dist.get_backend(group) == "nccl":      # a 1-rank RCCL group still executes the collective
         view = bucket[:n]
         if view.is_cuda and _host_staged(group):
             host = view.cpu()

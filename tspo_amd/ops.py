@@ -34,6 +34,23 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+import os as _os
+
+DEBUG_CHECKS = _os.environ.get("TSPO_DEBUG_CHECKS", "0") not in ("", "0")   # costs a host sync per call: off by default
+
+
+def _check_rollout_idx(ix: torch.Tensor, what: str, need_group: bool = False) -> None:
+    """The policy-gradient kernels find a frame's rollout membership by BINARY SEARCH in idx[b,g,:]: every rollout's
+    index list must be strictly ascending (what tspo_gumbel_topk / tspo_topk_sorted emit).  An unsorted external list (a
+    reference-style `ts_ids` in selection order) would give wrong gradients silently, so with DEBUG_CHECKS (or
+    TSPO_DEBUG_CHECKS=1) it is rejected here.  A group of one rollout has no spread (std of one value = NaN, as
+    torch.std gives): rejected where an advantage is formed."""
+    if need_group and ix.shape[1] < 2:
+        raise ValueError(f"{what}: G = {ix.shape[1]} rollout per prompt - the group-relative advantage needs G >= 2")
+    if DEBUG_CHECKS and ix.shape[-1] > 1 and not bool((ix[..., 1:] > ix[..., :-1]).all()):
+        raise ValueError(f"{what}: idx[b,g,:] must be strictly ascending (sort each rollout's frame list first)")
+
+
 # ---------------------------------------------------------------------------
 # samplers
 # ---------------------------------------------------------------------------
@@ -107,6 +124,7 @@ def pg_grad_logits(logp: torch.Tensor, idx: torch.Tensor, adv: torch.Tensor, sca
     ix = idx.to(torch.int64).contiguous()
     B, T = lp.shape
     _, G, k = ix.shape
+    _check_rollout_idx(ix, "pg_grad_logits")
     dl = torch.empty_like(lp)
     loss = torch.empty((B,), dtype=torch.float32, device=lp.device)
     check(_lib.lib().tspo_pg_grad_logits(_ptr(lp), _ptr(ix), _ptr(a), B, G, T, k, float(scale), _ptr(dl), _ptr(loss),
@@ -124,6 +142,7 @@ def grpo_pg_grad(rewards: torch.Tensor, logp: torch.Tensor, idx: torch.Tensor, s
     _, G, k = ix.shape
     if tuple(r.shape) != (B, G):
         raise ValueError(f"rewards {tuple(r.shape)} do not match idx {tuple(ix.shape)}")
+    _check_rollout_idx(ix, "grpo_pg_grad", need_group=True)
     adv = torch.empty_like(r)
     dl = torch.empty_like(lp)
     loss = torch.empty((B,), dtype=torch.float32, device=lp.device)
@@ -239,6 +258,7 @@ def policy_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, rewar
     _, G, k = ix.shape
     if tuple(r.shape) != (B, G) or tuple(lp.shape) != (B, T):
         raise ValueError(f"rewards {tuple(r.shape)} / logp {tuple(lp.shape)} do not match idx {tuple(ix.shape)}, feats {tuple(x.shape)}")
+    _check_rollout_idx(ix, "policy_backward", need_group=True)
     w = _sel_structs(flat, D, _lib.SelectorWeights)
     g = _sel_structs(flat_grad, D, _lib.SelectorGrads)
     adv = torch.empty_like(r)

@@ -191,7 +191,9 @@ class PolicyTrainer:
         ctx.consumed = True
         self._ws_pool.append(ctx.ws)
         ctx.ws = None
-        return {"loss": loss if self.grad_accum_steps == 1 else loss * self.grad_accum_steps, "advantages": adv}
+        # `loss` is the kernels' UNSCALED per-prompt -sum(adv*...)/G (only dL/dscores carries `scale`): callers average it
+        # over micro-steps themselves (train.py), so it is returned as is whatever grad_accum_steps is
+        return {"loss": loss, "advantages": adv}
 
     def at_boundary(self) -> bool:
         return self._micro >= self.grad_accum_steps

@@ -58,7 +58,14 @@ class _SelectorFn(torch.autograd.Function):
         scores, attn, ws = ops.selector_forward(flat, img, txt, clip, module.num_heads, window, tau)
         ctx.module, ctx.window, ctx.tau, ctx.ws = module, window, tau, ws
         ctx.save_for_backward(img, txt)
-        ctx.flat = flat
+        # the backward needs the weights THIS forward used.  Packed copy of non-flat parameters: it is repacked in place on
+        # the next forward, so this graph keeps a private copy (14 MB).  Flat mode: the live bucket is used and its
+        # version counter is recorded - an in-place update between forward and backward raises, as autograd does for
+        # any saved tensor ("modified by an inplace operation").
+        if module._is_flat():
+            ctx.flat, ctx.flat_version = flat, flat._version
+        else:
+            ctx.flat, ctx.flat_version = flat.clone(), None
         ctx.mark_non_differentiable(attn)
         return scores, attn
 
@@ -66,6 +73,9 @@ class _SelectorFn(torch.autograd.Function):
     def backward(ctx, dscores, _dattn):
         img, txt = ctx.saved_tensors
         m = ctx.module
+        if ctx.flat_version is not None and ctx.flat._version != ctx.flat_version:
+            raise RuntimeError("MultiModal_Align: the flat parameter bucket was modified in place between this forward and "
+                               "its backward (optimizer step / EMA swap with a graph still alive); run the forward again")
         fg = torch.zeros_like(ctx.flat)
         ops.selector_backward(ctx.flat, fg, img, txt, dscores.contiguous(), m.num_heads, ctx.window, ctx.tau, ctx.ws)
         offs = ops.flat_offsets(m.dim)

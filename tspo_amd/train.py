@@ -1,8 +1,11 @@
 """TSPO policy training driver on MI355X - what `train_deepspeed.sh` + `src/open_tspo/tspo.py` +
 `LLaVAVideoTSPOTrainer` do for the temporal agent, without DeepSpeed / TRL:
 
+    python -m tspo_amd.train --gpus 8 --features /data/tspo_feats --output-dir ckpt/tspo --max-steps 1000
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
         -m tspo_amd.train --features /data/tspo_feats --output-dir ckpt/tspo --max-steps 1000
+
+(the first form spawns its own ranks, tspo_amd.dist.self_spawn; the second is what train_deepspeed.sh:14-16 does).
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Only the 2.95 M selector parameters train,
 so the whole exchange is ONE all-reduce of the flat fp32 gradient bucket per optimizer step (`PolicyTrainer`) plus one
@@ -76,8 +79,9 @@ class SyntheticFeatures:
         self.signal = float(signal)
         self.T, self.D, self.seed, self.dev = T, D, seed, torch.device(device)
 
-    def batches(self, rank: int, world: int, bs: int) -> Iterator[Batch]:
-        i = 0
+    def batches(self, rank: int, world: int, bs: int, skip: int = 0) -> Iterator[Batch]:
+        """`skip` = micro-batches already consumed (resume): an index advance, nothing is materialised for them."""
+        i = int(skip)
         while True:
             g = torch.Generator(device=self.dev).manual_seed(self.seed * 1_000_003 + (i * world + rank))
             f = torch.randn(bs, self.T, self.D, generator=g, device=self.dev)
@@ -100,17 +104,20 @@ class FeatureCacheDataset:
             raise FileNotFoundError(f"no *.pth feature caches under {root}")
         self.dev = torch.device(device)
 
-    def batches(self, rank: int, world: int, bs: int) -> Iterator[Batch]:
+    def batches(self, rank: int, world: int, bs: int, skip: int = 0) -> Iterator[Batch]:
+        """`skip` = micro-batches already consumed (resume): the file cursor advances, no file is read for them."""
         assert bs == 1, "videos differ in length: one prompt per micro-batch, like the reference (per_device_train_batch_size 1)"
         mine = [self.files[i] for i in tdist.shard_prompts(len(self.files), world, rank)] or self.files
+        pos = int(skip) % len(mine)
         while True:
-            for path in mine:
+            for path in mine[pos:]:
                 stat = torch.load(path, map_location="cpu")
                 img = stat["image"].to(self.dev).float()[None]
                 txt = stat["text"].to(self.dev).float().reshape(1, -1, img.shape[-1])[:, :1]
                 clip = stat["clip_scores"].to(self.dev).float().reshape(1, -1)
                 mask = stat.get("mask", torch.ones(img.shape[1], dtype=torch.bool)).to(self.dev).reshape(1, -1)
                 yield Batch(img, txt, clip, mask, stat.get("type", "specific"), {"path": path})
+            pos = 0
 
 
 def mask_reward_model(idx: torch.Tensor, batch: Batch) -> torch.Tensor:
@@ -151,9 +158,12 @@ def train(cfg: TrainConfig, data, reward_model: Callable[[torch.Tensor, Batch], 
           log: Optional[Callable[[Dict], None]] = None, stop_after: Optional[int] = None) -> Dict:
     """Runs cfg.max_steps optimizer steps on this rank's shard (resuming from the newest checkpoint in cfg.output_dir);
     returns the last logged metrics.  `stop_after` ends the run early after that global step, with a checkpoint (tests)."""
-    rank, world, local = tdist.init_from_env(backend)
+    import torch.distributed as dist
+    world_env, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device("cuda", local if torch.cuda.device_count() > local else 0)
     torch.cuda.set_device(dev)
+    own_group = world_env > 1 and not dist.is_initialized()
+    rank, world, local = tdist.init_from_env(backend, device=dev)
     if flat is None:
         g = torch.Generator(device=dev).manual_seed(cfg.seed)            # HF _init_weights: N(0, 0.02), zero bias
         offs = ops.flat_offsets(cfg.dim)
@@ -171,9 +181,8 @@ def train(cfg: TrainConfig, data, reward_model: Callable[[torch.Tensor, Batch], 
         start = int(json.load(open(os.path.join(last, "trainer_state.json")))["global_step"])
     os.makedirs(cfg.output_dir, exist_ok=True)
     logf = open(os.path.join(cfg.output_dir, "metrics.jsonl"), "a") if rank == 0 else None
-    it = data.batches(rank, world, cfg.per_device_train_batch_size)
-    for _ in range(start * cfg.gradient_accumulation_steps):                   # deterministic data order across resumes
-        next(it)
+    # deterministic data order across resumes: the stream starts at the first micro-batch not yet consumed
+    it = data.batches(rank, world, cfg.per_device_train_batch_size, skip=start * cfg.gradient_accumulation_steps)
     last_metrics: Dict = {}
     t0 = time.perf_counter()
     for step in range(start, cfg.max_steps):
@@ -215,6 +224,12 @@ def train(cfg: TrainConfig, data, reward_model: Callable[[torch.Tensor, Batch], 
             break
     if logf:
         logf.close()
+    if world > 1:
+        # nobody leaves while rank 0 is still writing the last checkpoint (a launcher would tear the job down)
+        torch.cuda.synchronize()
+        dist.barrier()
+        if own_group:
+            dist.destroy_process_group()
     last_metrics["flat"] = trainer.flat
     return last_metrics
 
@@ -224,10 +239,14 @@ def main(argv=None):
     ap.add_argument("--features", default=None, help="directory of feature-cache .pth files (default: synthetic features)")
     ap.add_argument("--frames", type=int, default=512, help="T of the synthetic features")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--gpus", type=int, default=0, help="ranks to run; without a launcher (no WORLD_SIZE) the driver spawns them itself")
     ap.add_argument("--no-resume", action="store_true")
     for name, val in asdict(TrainConfig()).items():
         ap.add_argument("--" + name.replace("_", "-"), type=type(val), default=val)
     a = ap.parse_args(argv)
+    if a.gpus > 1 and not tdist.launched_by_torchrun():
+        import sys
+        return tdist.self_spawn(a.gpus, [""] + list(sys.argv[1:] if argv is None else argv), module="tspo_amd.train")
     cfg = TrainConfig(**{k: getattr(a, k) for k in asdict(TrainConfig())})
     data = FeatureCacheDataset(a.features) if a.features else SyntheticFeatures(T=a.frames, D=cfg.dim, seed=cfg.seed)
     m = train(cfg, data, backend=a.backend, resume=not a.no_resume,
