@@ -27,6 +27,14 @@
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// Development hooks (python -m tspo_amd.build --dev only): epilogue ablations selected at run time through GemmArgs.P and
+// an s_memtime probe of the tile phases (DEV bit 0 of the kernel template).  The shipped library compiles none of it.
+#ifdef TSPO_DEV_HOOKS
+#define A7_ABL(g, n) ((g).P == -(n))
+#else
+#define A7_ABL(g, n) false
+#endif
+
 namespace {
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -96,6 +104,12 @@ template <int EPI, bool FULL>
 __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0, int wm, int wn, int l15, int q4,
                                               const EpiPre& p0) {
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first v_accvgpr_read
+#ifdef TSPO_DEV_HOOKS
+  if (g.P <= -10) {   // A/B: the four waves enter the epilogue (-P - 9) x 64 cycles apart instead of in lock-step
+    const int w = wm * 2 + wn;
+    for (int i = 0; i < w * (-g.P - 9); ++i) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
   constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
   constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
   float2 rst[8];
@@ -142,6 +156,13 @@ __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0,
         }
         if (nhs == 0) rload(mi, wn * 2 + 1);
       }
+#ifdef TSPO_DEV_HOOKS
+      if (nhs == 1 && A7_ABL(g, 3)) {   // ablation: slice 1 computed but not stored (what deferring its stores could save)
+        GemmArgs h = g;
+        h.M = 0;
+        g3_epi_row<EPI, true, false>(h, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
+      } else
+#endif
       g3_epi_row<EPI, true, FULL>(g, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
     });
   });
@@ -149,7 +170,10 @@ __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0,
 
 // A2: A staged two K-steps ahead in two register sets (else one set, one K-step ahead).  PRE0: slice 0's small epilogue
 // inputs are requested behind the tile's last K-step (else at the start of the epilogue).  Both cost VGPRs.
-template <int EPI, bool A2, bool PRE0>
+// RW ("relaxed waits"): no lgkmcnt(0) drain between a K-step's [B] half and the next K-step's [A] half - there is no
+// barrier there, so only the register dependencies of the first MFMAs have to be met and the last ds_write / W-fragment
+// read of [B] may still be in flight when [A] starts.  DEV: development probes (0 in the shipped library).
+template <int EPI, bool A2, bool PRE0, bool RW = false, int DEV = 0>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int tilesM, int ngrp) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE];  // the ONLY LDS object
   const int tid = threadIdx.x, lane = tid & 63;
@@ -163,6 +187,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
   const int ntile_x = panels * n_per;
   const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
   if (my_tiles == 0) return;
+#ifdef TSPO_DEV_HOOKS
+  if (DEV & 6) {   // A/B: workgroups of an XCD start out of phase (wl x 0.2 us / 0.4 us), spreading the XCD's store bursts
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)wl * ((DEV & 2) ? 20 : 40);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   A4_FENCE();   // claims a[0:255] for this kernel
 
   // ---- staging registers: this wave's 8 W pieces of a stage (one set, loaded ONE K-step ahead: W is re-read by every
@@ -192,14 +222,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
   __amdgpu_buffer_rsrc_t a_rs = rsrc_a(a_s), w_rs = rsrc_w(w_s);
   auto adv_a = [&]() { if (++a_kt == nk) { a_kt = 0; a_s += nwl; a_rs = rsrc_a(a_s); } };
   auto adv_w = [&]() { if (++w_kt == nk) { w_kt = 0; w_s += nwl; w_rs = rsrc_w(w_s); } };
+  // DEV bits 3 / 4 (timing experiments only, wrong results): the W / A operand addressed as if stored in 8-row x 64-column
+  // blocks of 1 KB (a staging piece = ONE contiguous KB instead of 8 rows of 128 B at a pitch of 2*K bytes)
+  const unsigned lane_boff = (unsigned)lane * 16u;
   auto gload_a = [&](auto q_, u32x4 (&sa)[8]) {
     constexpr int q = decltype(q_)::value;
-    sa[q] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, lane_goff + (unsigned)a_kt * (GT_BK * 2u),
+    sa[q] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (DEV & 16) ? lane_boff + (unsigned)a_kt * 1024u : lane_goff + (unsigned)a_kt * (GT_BK * 2u),
                                                   (unsigned)(wid * 8 + q) * piece_stride, 0);
   };
   auto gload_w = [&](auto q_) {
     constexpr int q = decltype(q_)::value;
-    sw_[q] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane_goff + (unsigned)w_kt * (GT_BK * 2u),
+    sw_[q] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, (DEV & 8) ? lane_boff + (unsigned)w_kt * 1024u : lane_goff + (unsigned)w_kt * (GT_BK * 2u),
                                                    (unsigned)(wid * 8 + q) * piece_stride, 0);
   };
   auto swrite_a = [&](auto q_, const u32x4 (&sa)[8], int buf) {
@@ -295,11 +328,24 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
       if (decltype(ph_)::value == 0) swrite_a(j_, sa, cb); else gload_a(j_, sa);
     });
     adv_a();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (!RW) __builtin_amdgcn_s_waitcnt(0xC07F);
     ++it;
   };
+#ifdef TSPO_DEV_HOOKS
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos));
+  auto probe = [&](int t, int i) {
+    if ((DEV & 1) && t < 24) {
+      const unsigned long long c = __builtin_amdgcn_s_memtime();
+      if (tid == 0) dbg[((size_t)blockIdx.x * 24 + t) * 6 + i] = c;
+      if (i == 0) { const unsigned long long r = __builtin_amdgcn_s_memrealtime(); if (tid == 0) dbg[((size_t)blockIdx.x * 24 + t) * 6 + 5] = r; }
+    }
+  };
+#else
+  auto probe = [&](int, int) {};
+#endif
   for (int t = 0; t < my_tiles; ++t) {   // nk even: K-step kt of a tile always uses A register set kt & 1
-    const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
+    int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
+    probe(t, 0);
     kstep(std::true_type{}, sa0);                              // first K-step: its K-half 0 starts the accumulators (C = 0)
     for (int kt = 1; kt < nk - 1; kt += 2) {
       kstep(std::false_type{}, A2 ? sa1 : sa0);
@@ -309,8 +355,18 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     if (PRE0) epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
     kstep(std::false_type{}, A2 ? sa1 : sa0);
     if (!PRE0) epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
+    probe(t, 1);
+#ifdef TSPO_DEV_HOOKS
+    if (A7_ABL(g, 2)) { m0 = blockIdx.x * G3_BM; n0 = 0; }     // every tile of this workgroup stores to (and reads its residual from) ONE hot tile
+    if (A7_ABL(g, 1)) {                                        // epilogue arithmetic only: no stores, no residual loads
+      GemmArgs h = g;
+      h.M = 0;
+      agpr_epilogue<EPI, false>(h, m0, n0, wm, wn, l15, q4, p0);
+    } else
+#endif
     if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
     else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
+    probe(t, 2);
     c_s += nwl;
     // the next tile's first fragments again, AFTER the epilogue: the copies read in the last [B] are dead here, so
     // nothing but the staging registers stays live across the epilogue (stale data after the last tile, never used)
@@ -318,20 +374,27 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     read_a(nbuf, 0, fa0);
     read_w_all(nbuf, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    probe(t, 3);
   }
 }
 
-template <int EPI, bool A2, bool PRE0>
+template <int EPI, bool A2, bool PRE0, bool RW = false, int DEV = 0>
 int launch_gemm_a7(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
   g.tilesN = (g.N + G3_BN - 1) / G3_BN;
   g.nwg = tilesM * g.tilesN;
   int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
   if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
-  hipLaunchKernelGGL((gemm_bf16_a7_kernel<EPI, A2, PRE0>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
+  hipLaunchKernelGGL((gemm_bf16_a7_kernel<EPI, A2, PRE0, RW, DEV>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
   return tspo::check_launch("gemm_bf16_a7");
 }
 }  // namespace
+
+#ifdef TSPO_DEV_HOOKS
+static void* g_dev_debug = nullptr;
+extern "C" void tspo_dev_set_debug(void* p) { g_dev_debug = p; }
+static void* tspo_dev_debug_ptr() { return g_dev_debug; }
+#endif
 
 namespace {
 template <int EPI>
@@ -340,6 +403,31 @@ int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
     return tspo::set_err(TSPO_EINVAL, "gemm_agpr: K=%d must be a multiple of 128", g.K);
 #ifdef TSPO_DEV_HOOKS
   if (g.variant == 83) return launch_gemm_a7<EPI, true, false>(g, st);    // A/B: A two K-steps ahead, no early epilogue prefetch
+  if (g.variant == 84) return launch_gemm_a7<EPI, false, true, true>(g, st);   // A/B: relaxed waits between [B] and the next [A]
+  if (g.variant == 85) {                                                  // tile-phase probe (s_memtime): needs tspo_dev_set_debug()
+    GemmArgs h = g;
+    h.pos = reinterpret_cast<const float*>(tspo_dev_debug_ptr());
+    if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_agpr: variant 85 without a debug buffer");
+    return launch_gemm_a7<EPI, false, true, false, 1>(h, st);
+  }
+  if (g.variant == 88) return launch_gemm_a7<EPI, false, true, false, 2>(g, st);   // staggered start, 6.4 us across an XCD's workgroups
+  if (g.variant == 89) return launch_gemm_a7<EPI, false, true, false, 4>(g, st);   // staggered start, 12.8 us
+  if (g.variant == 90) {                                                  // tile-phase probe of the staggered kernel
+    GemmArgs h = g;
+    h.pos = reinterpret_cast<const float*>(tspo_dev_debug_ptr());
+    if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_agpr: variant 90 without a debug buffer");
+    return launch_gemm_a7<EPI, false, true, false, 5>(h, st);
+  }
+  if (g.variant == 81) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true>(h, st); }   // slice 1 of every tile not stored
+  if (g.variant >= 91 && g.variant <= 94) {   // epilogue entry de-phased by 128 / 256 / 512 / 1024 cycles per wave
+    GemmArgs h = g;
+    h.P = -9 - (2 << (g.variant - 91));
+    return launch_gemm_a7<EPI, false, true>(h, st);
+  }
+  if (g.variant == 95) return launch_gemm_a7<EPI, false, true, false, 8>(g, st);    // timing only: W addressed as 1 KB blocks
+  if (g.variant == 96) return launch_gemm_a7<EPI, false, true, false, 24>(g, st);   // timing only: W and A addressed as 1 KB blocks
+  if (g.variant == 86) { GemmArgs h = g; h.P = -1; return launch_gemm_a7<EPI, false, true>(h, st); }   // epilogue without memory traffic
+  if (g.variant == 87) { GemmArgs h = g; h.P = -2; return launch_gemm_a7<EPI, false, true>(h, st); }   // epilogue to / from one hot tile per workgroup
 #endif
   return launch_gemm_a7<EPI, false, true>(g, st);
 }
