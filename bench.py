@@ -271,6 +271,7 @@ def main():
     ap.add_argument("--rollout-cfg", default="4,512,8,16", help="B,T,G,k of the policy step (configs[2]: 4,512,8,16; configs[4] stress: 1,4096,16,16)")
     ap.add_argument("--no-pruned", action="store_true", help="skip the extra (non-headline) run with the pruned last block")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: stand-alone LayerNorm passes instead of folding them into the GEMMs")
+    ap.add_argument("--no-720p", action="store_true", help="skip the extra (non-headline) run that starts from 720p uint8 frames")
     ap.add_argument("--no-comm-probe", action="store_true", help="skip the RCCL probe (init + timed all-reduce of the gradient bucket)")
     a = ap.parse_args()
 
@@ -359,6 +360,33 @@ def main():
         assert bool((out["idx"][:, 1:] > out["idx"][:, :-1]).all())
         score_step()   # restore the full-model outputs used by the checks below
 
+    # ---- non-headline: the real front end of the path (temporal_agent.py:156-164): 1280x720 uint8 frames in HBM ->
+    # Pillow-exact antialiased bicubic resize + centre crop on the GPU (tspo_preprocess_frames) -> the same scoring path ----
+    from_720p = None
+    if not a.no_720p:
+        from tspo_amd import preprocess as PP
+        raw = torch.randint(0, 256, (T, 720, 1280, 3), generator=g, device=dev, dtype=torch.uint8)     # one video's frames
+
+        def raw_step():
+            px = PP.preprocess_frames(raw)
+            out["idx720"], _, _ = scorer(px[None], txt[:1], k)
+
+        rsec_ = timed(raw_step, a.steps, 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        PP.preprocess_frames(raw)
+        e0.record()
+        for _ in range(5):
+            PP.preprocess_frames(raw)
+        e1.record()
+        torch.cuda.synchronize()
+        pre_ms = e0.elapsed_time(e1) / 5
+        from_720p = {"frames_scored_per_s": round(T * world * a.steps / rsec_, 2), "preprocess_ms": round(pre_ms, 3),
+                     "preprocess_input_TBps": round(raw.numel() / (pre_ms * 1e-3) / 1e12, 3),
+                     "note": "1280x720 uint8 THWC frames resident in HBM -> on-device CLIPImageProcessor-exact resize + crop -> "
+                             "same scoring path (one video per GPU); not used for `value` (SURVEY 8d defines it on 224x224 pixels)"}
+        assert bool((out["idx720"][:, 1:] > out["idx720"][:, :-1]).all())
+        del raw
+
     # ---- split: score + select only (features resident), SURVEY 8(d) ----------
     feats_res = scorer.encode(pixels)
 
@@ -446,6 +474,7 @@ def main():
                 "frames_scored_per_s": round(pruned_fps, 2),
                 "note": "opt-in ops.clip_vit_forward(prune_last_layer=True): last block for the class-token row only "
                         "(same features); not used for `value`"},
+            "frames_scored_per_s_from_720p_u8": from_720p,
             "split_ms": {"encode": round(sec / a.steps * 1e3 - sel_sec * 1e3, 3), "score_select": round(sel_sec * 1e3, 3)},
             "roofline": roof, "cpu_baseline": cpu, "comm": comm,
             "launcher": "torch.distributed.run" if (world > 1 and not os.environ.get("TSPO_SELF_SPAWNED")) else

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TSPO_ABI_VERSION 2
+#define TSPO_ABI_VERSION 3
 
 enum tspo_error {
   TSPO_OK = 0,
@@ -187,6 +187,22 @@ int tspo_policy_backward(const tspo_selector_weights* w, const float* img, const
                          const tspo_selector_grads* grads, float* adv, float* loss,
                          void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags);
 
+/* tspo_policy_backward that also leaves the sum of squares of the gradient it
+ * wrote (all six trainable tensors) as *n_partials <= 512 block partials in
+ * norm_partials (f32, >= 512 floats), for tspo_adamw_clip_step_ex: the
+ * clip_grad_norm_ of the HF Trainer (tspo_trainer.py via Trainer.training_step)
+ * then costs no pass of its own.  Only valid while the gradient bucket is not
+ * modified between the two calls (single rank, no gradient accumulation);
+ * otherwise use tspo_adamw_clip_step.  norm_partials == NULL: plain
+ * tspo_policy_backward.                                                     */
+int tspo_policy_backward_ex(const tspo_selector_weights* w, const float* img, const float* txt,
+                            const float* rewards, const float* logp, const int64_t* idx,
+                            int B, int T, int D, int H, int M, int window, float tau,
+                            int G, int k, float adv_eps, float scale,
+                            const tspo_selector_grads* grads, float* adv, float* loss,
+                            void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags,
+                            float* norm_partials, int* n_partials);
+
 /* ------------------------------------------------------------------------
  * Optimiser on the flat parameter bucket
  * ------------------------------------------------------------------------ */
@@ -214,6 +230,13 @@ int tspo_adamw_clip_step(float* param, const float* grad, float* m, float* v, si
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float pre_scale, float max_norm, float* out2,
                          void* workspace, size_t workspace_bytes, tspo_stream_t stream);
+
+/* tspo_adamw_clip_step with the partial sums of squares of `grad` supplied by
+ * the kernel that produced it (tspo_policy_backward_ex): ONE launch.        */
+int tspo_adamw_clip_step_ex(float* param, const float* grad, float* m, float* v, size_t n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                            float pre_scale, float max_norm, float* out2,
+                            const float* norm_partials, int n_partials, tspo_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * CLIP ViT vision tower + projection  (frame encoder)

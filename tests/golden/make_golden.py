@@ -304,6 +304,39 @@ def gen_glue(_out):
         hay.append({"L": L, "repeat_times": rep, "n_wrong": n_wrong, "sample_len": sample_len, "seed": seed,
                     "frame_ids": merged[:, 0, 0, 0].tolist(), "mask": mask.numpy().astype(int).tolist()})
     g["haystack"] = hay
+
+    # ---- frame-index join (mp_tools/change_score_tch.py): the reference's flat script itself, run on temp files.  Inputs
+    #      (annotation list, results {index: [frame numbers]}) and the JSON text it writes are recorded. ----
+    import pickle
+    import subprocess
+    import tempfile
+    joins = []
+    cases = [
+        ("VideoMME", "videomme", [{"question_id": "001-1", "video": "a.mp4", "duration": "short"},
+                                  {"question_id": "001-2", "video": "a.mp4"}, {"question_id": "777-3", "video": "z.mp4"}],
+         [["001-1", [0.0, 30.0, 61.0, 1502.0]], ["777-3", [12.0]], ["unused", [1.0]]]),
+        ("MLVU", "mlvu", [{"question_id": 5, "question": "q?"}, {"question_id": 6, "question": "r?"}],
+         [[6, [3.0, 4.5]], [5, []]]),
+        ("LongVideoBench", "lvb_val", [{"id": "abc", "question_id": "ignored"}, {"id": "def"}, {"id": 9}],
+         [["def", [100.0, 250.0]], [9, [0.0]], ["ignored", [7.0]]]),
+    ]
+    for data, json_name, anno, results in cases:
+        with tempfile.TemporaryDirectory() as td:
+            os.makedirs(os.path.join(td, "evaluation", "jsons"))
+            os.makedirs(os.path.join(td, "evaluation", "jsons_idx"))
+            os.makedirs(os.path.join(td, "work_dir"))
+            with open(os.path.join(td, "evaluation", "jsons", f"{json_name}.json"), "w") as f:
+                json.dump(anno, f)
+            with open(os.path.join(td, "work_dir", f"run7_{data}_supp.pkl"), "wb") as f:
+                pickle.dump({k: v for k, v in results}, f)
+            r = subprocess.run([sys.executable, "/root/reference/mp_tools/change_score_tch.py", "--base_anno_path",
+                                os.path.join(td, "evaluation"), "--data", data, "--name", "run7"], cwd=td, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            out_text = open(os.path.join(td, "evaluation", "jsons_idx", f"run7_{data}_frameIdx.json")).read()
+        joins.append({"data": data, "json_name": json_name, "name": "run7", "anno": anno, "results": results,
+                      "written_relpath": os.path.join("jsons_idx", f"run7_{data}_frameIdx.json"), "written_text": out_text,
+                      "printed_missing": r.stdout.split()})
+    g["frame_idx_join"] = joins
     path = os.path.join(HERE, "glue.json")
     with open(path, "w") as f:
         json.dump(g, f, indent=0)

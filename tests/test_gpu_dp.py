@@ -149,6 +149,37 @@ def test_gradient_accumulation_equals_concatenated_batch():
     assert abs(st["lr"] - 5e-4) < 1e-12 and abs(sch.current_lr() - 4.5e-4) < 1e-12
 
 
+def test_fused_gradient_norm_equals_the_separate_pass(monkeypatch):
+    """Single rank, no accumulation: the backward's split reduction also leaves the bucket's sum of squares
+    (tspo_policy_backward_ex -> tspo_adamw_clip_step_ex, one launch less, no second pass over the gradient).  Same
+    gradient bit for bit, same norm / clip coefficient / parameters as the separate sum-of-squares pass to rounding
+    (different summation order); any path on which the bucket can change in between keeps the separate pass."""
+    f, t, c, noise, rew = (x.to(DEV) for x in _batch(0))
+    seen = []
+    real = ops.adamw_clip_step
+    monkeypatch.setattr(ops, "adamw_clip_step", lambda *a, **k: (seen.append(k.get("norm_partials") is not None), real(*a, **k))[1])
+    fused = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W, max_grad_norm=MAX_NORM)
+    sf = fused.step(f, t, c, lambda idx: rew, G, K, TAU, noise=noise)
+    sep = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W, max_grad_norm=MAX_NORM, reduce_fn=lambda bucket, n, group: 1)
+    ss = sep.step(f, t, c, lambda idx: rew, G, K, TAU, noise=noise)
+    acc = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W, max_grad_norm=MAX_NORM, grad_accum_steps=2)
+    acc.step(f[:2], t[:2], c[:2], lambda idx: rew[:2], G, K, TAU, noise=noise[:2])
+    acc.step(f[2:], t[2:], c[2:], lambda idx: rew[2:], G, K, TAU, noise=noise[2:])
+    assert seen == [True, False, False]
+    assert torch.equal(fused.grad, sep.grad)
+    nf, ns = sf["grad_norm_scale"].cpu().numpy(), ss["grad_norm_scale"].cpu().numpy()
+    np.testing.assert_allclose(nf, ns, rtol=2e-6)
+    assert nf[1] < 0.5                                                      # the clip is active
+    ref_norm = float(torch.linalg.vector_norm(sep.grad[: sep.n_train].double()))
+    assert abs(nf[0] - ref_norm) <= 2e-6 * ref_norm
+    n = fused.n_train
+    np.testing.assert_allclose(fused.flat[:n].cpu().numpy(), sep.flat[:n].cpu().numpy(), rtol=1e-5, atol=1e-9)
+    # a second step reuses nothing stale: partial count is consumed by optimizer_step
+    assert fused._norm_np == 0
+    fused.step(f, t, c, lambda idx: rew, G, K, TAU, noise=noise)
+    assert seen[-1] is True
+
+
 def test_rollout_context_is_validated():
     f, t, c, noise, rew = (x.to(DEV) for x in _batch(1))
     tr = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W)

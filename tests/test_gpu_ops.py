@@ -85,6 +85,38 @@ def test_topk_sorted_long_video_beyond_lds():
             assert got[b].tolist() == O.topk_sorted(s[b], k).tolist(), (T, k, b)
 
 
+def test_gumbel_topk_long_rows_beyond_lds():
+    """Rollouts over rows longer than the 16384 keys that fit in LDS (round 3: global-key path, the perturbed logit is
+    recomputed per pass): injected noise -> the oracle's indices / logp / straight-through probs, in-kernel Philox noise ->
+    the indices the oracle picks on the noise the kernel reports, and the same indices as the LDS path gives on a row
+    that is extended past the limit with -inf logits."""
+    B, G, T, k = 2, 3, 20000, 48
+    logits = synth.normal((B, T), 91, 3.0)
+    u = np.clip(synth.uniform((B, G, T), 92), 1e-6, 1 - 1e-6)
+    noise = (-np.log(-np.log(u))).astype(np.float32)
+    out = ops.gumbel_topk(G_(logits), k, G, noise=G_(noise), want_probs=True)
+    for b in range(B):
+        for g in range(G):
+            idx, probs, lp = O.gumbel_topk(T_(logits[b]), T_(noise[b, g]), k)
+            assert out["idx"][b, g].cpu().tolist() == idx.tolist(), (b, g)
+            np.testing.assert_allclose(out["probs"][b, g].cpu().numpy(), probs.numpy(), rtol=0, atol=2e-6)
+        _check_logp(out["logp"][b].cpu().numpy(), lp.numpy())
+    ph = ops.gumbel_topk(G_(logits), k, G, seed=11, offset=3, want_noise=True)
+    pn = ph["noise"].cpu().numpy()
+    np.testing.assert_allclose(pn, O.gumbel_noise_philox(B, G, T, 11, 3), rtol=2e-5, atol=2e-5)
+    for b in range(B):
+        for g in range(G):
+            assert ph["idx"][b, g].cpu().tolist() == O.gumbel_topk(T_(logits[b]), T_(pn[b, g]), k)[0].tolist()
+    # the two code paths agree: a 16000-frame row (LDS-resident) == the same row padded to 17000 frames with -inf
+    short = synth.normal((1, 16000), 93, 3.0)
+    sn = noise[:1, :, :16000]
+    padded = np.concatenate([short, np.full((1, 1000), -np.inf, np.float32)], 1)
+    pnoise = np.concatenate([sn, np.zeros((1, G, 1000), np.float32)], 2)
+    a = ops.gumbel_topk(G_(short), k, G, noise=G_(sn))["idx"]
+    b_ = ops.gumbel_topk(G_(padded), k, G, noise=G_(pnoise))["idx"]
+    assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("case", GUMBEL_CASES, ids=[c[0] for c in GUMBEL_CASES])
 def test_gumbel_topk_injected_noise(golden, case):
     name, T, k, G, scale = case

@@ -239,6 +239,7 @@ def test_bench_accounting_helpers():
     assert abs(g / 1e9 - 155.53) < 0.01 and abs(a / 1e9 - 6.49) < 0.01 and abs((g + a) / 1e9 - 162.03) < 0.02
     assert abs(bench.alg_bytes_per_launch(c, 1024) / 1e9 - 2.39) < 0.01
     r = bench.policy_step_roofline(4, 512, 768, 4e-4)
-    assert r["bound"] == "mfma" and r["dtype"] == "f32" and r["launches_per_step"] == bench.POLICY_STEP_LAUNCHES
+    assert r["bound"] == "mfma" and r["dtype"] == "f32" and r["launches_per_step"] is None      # counted live on the GPU only
+    assert bench.policy_step_roofline(4, 512, 768, 4e-4, 15, {"x": 15.0})["launches_per_step"] == 15
     assert abs(r["gemm_flop_per_step"] / 1e9 - 28.99) < 0.01
     assert abs(r["achieved"] - 28.99e9 / 4e-4 / 1e12) < 0.1 and abs(r["frac"] - r["achieved"] / 157.3) < 1e-3

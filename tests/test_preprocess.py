@@ -57,17 +57,27 @@ def test_processor_config_detection():
     assert not P.processor_is_default_clip(object())
 
 
+GPU_SIZES = SIZES + [(720, 1280), (433, 577), (224, 1000), (2160, 3840)]    # + 720p (bench geometry), odd pitch, wide crop, 4K
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("hw", SIZES, ids=[f"{h}x{w}" for h, w in SIZES])
+@pytest.mark.parametrize("hw", GPU_SIZES, ids=[f"{h}x{w}" for h, w in GPU_SIZES])
 def test_gpu_preprocess_bit_exact(hw):
     H, W = hw
-    T = 3
+    T = 3 if H * W < 2000 * 2000 else 1
     frames = synth.uniform_u8((T, H, W, 3), 55 + H + W)
     ref = O.clip_preprocess_u8(frames)
     got = P.preprocess_frames(torch.from_numpy(frames).cuda()).cpu().numpy()
     np.testing.assert_array_equal(got, ref)
     chw = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 3, 1, 2))).cuda()     # qwen25vl-style [T,3,H,W]
     np.testing.assert_array_equal(P.preprocess_frames(chw).cpu().numpy(), ref)
+    # a tensor that does not start on a 4-byte boundary (view into a larger buffer): the LDS-staged loads realign per row
+    big = torch.zeros(frames.size + 8, dtype=torch.uint8, device="cuda")
+    for off in (1, 3):
+        view = big[off:off + frames.size].view(T, H, W, 3)
+        view.copy_(torch.from_numpy(frames).cuda())
+        assert view.data_ptr() % 4 == off
+        np.testing.assert_array_equal(P.preprocess_frames(view).cpu().numpy(), ref)
 
 
 @pytest.mark.gpu

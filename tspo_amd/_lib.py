@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(PKG, "libtspo_hip.so")
 
 TSPO_F32, TSPO_BF16, TSPO_F16, TSPO_U8 = 0, 1, 2, 3
 TSPO_CLIP_NO_LN_FOLD, TSPO_CLIP_PRUNE_LAST = 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = C.c_void_p
 _i = C.c_int
@@ -63,9 +63,12 @@ SIGNATURES = {
                                        C.POINTER(SelectorGrads), _p, _sz, _p, _i]),
     "tspo_policy_backward": (_i, [C.POINTER(SelectorWeights), _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f,
                                   C.POINTER(SelectorGrads), _p, _p, _p, _sz, _p, _i]),
+    "tspo_policy_backward_ex": (_i, [C.POINTER(SelectorWeights), _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f, _f,
+                                     C.POINTER(SelectorGrads), _p, _p, _p, _sz, _p, _i, _p, C.POINTER(C.c_int)]),
     "tspo_grad_norm_scale": (_i, [_p, _sz, _f, _f, _p, _p, _sz, _p]),
     "tspo_adamw_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _p, _p]),
     "tspo_adamw_clip_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _f, _p, _p, _sz, _p]),
+    "tspo_adamw_clip_step_ex": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _f, _p, _p, _i, _p]),
     "tspo_clip_workspace_bytes": (_sz, [C.POINTER(ClipConfig), _i]),
     "tspo_clip_vit_forward": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p]),
     "tspo_clip_vit_forward_ex": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p, _i]),

@@ -237,7 +237,10 @@ extern "C" int tspo_binmax(const float* scores, int B, int T, int k, int64_t* id
 }
 
 // ---------------------------------------------------------------------------
-// Gumbel-top-k for all (prompt, rollout) pairs in one launch
+// Gumbel-top-k for all (prompt, rollout) pairs in one launch.  LONG (T > SEL_LDS_KEYS): the row does not fit in LDS, so the
+// perturbed logit z(t) - a pure function of (logit, injected noise or the Philox counter) - is recomputed on each of the
+// selection's passes, like the global-key path of topk_sorted_kernel; results are identical to the LDS-resident form.
+template <bool LONG>
 __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
     const float* __restrict__ logits, const float* __restrict__ noise, uint32_t key0, uint32_t key1, uint32_t off_lo,
     int G, int T, int k, float tau, int64_t* __restrict__ idx, float* __restrict__ logp, float* __restrict__ probs,
@@ -248,22 +251,28 @@ __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* l = logits + (size_t)b * T;
   const size_t row = ((size_t)b * G + g) * T;
-  float* zbuf = reinterpret_cast<float*>(lds_keys + T);
+  float* zbuf = reinterpret_cast<float*>(lds_keys + (LONG ? 0 : T));
+  auto gnoise = [&](int t) {
+    return noise ? noise[row + t] : gumbel_from_bits(philox_x0((uint32_t)t, (uint32_t)g, (uint32_t)b, off_lo, key0, key1));
+  };
+  auto zf = [&](int t) { return (l[t] + gnoise(t)) / tau; };
   float zmax = -INFINITY, lmax = -INFINITY;
   for (int t = tid; t < T; t += SEL_THREADS) {
-    float gn;
-    if (noise) gn = noise[row + t];
-    else gn = gumbel_from_bits(philox_x0((uint32_t)t, (uint32_t)g, (uint32_t)b, off_lo, key0, key1));
+    const float gn = gnoise(t);
     if (noise_out) noise_out[row + t] = gn;
     const float lv = l[t];
     const float z = (lv + gn) / tau;
-    lds_keys[t] = order_key(z);
-    if (probs) zbuf[t] = z;
+    if (!LONG) {
+      lds_keys[t] = order_key(z);
+      if (probs) zbuf[t] = z;
+    }
     zmax = fmaxf(zmax, z);
     lmax = fmaxf(lmax, lv);
   }
   __syncthreads();
-  {
+  if (LONG) {
+    select_topk_sorted([&](int t) { return order_key(zf(t)); }, T, k, idx + ((size_t)b * G + g) * k, sh);
+  } else {
     const uint32_t* kp = lds_keys;
     select_topk_sorted([kp](int t) { return kp[t]; }, T, k, idx + ((size_t)b * G + g) * k, sh);
   }
@@ -278,12 +287,12 @@ __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
   if (probs) {  // (one_hot - y) + y with y = softmax(z)  (model/utils.py:74-75)
     zmax = block_max(zmax, red);
     float se = 0.f;
-    for (int t = tid; t < T; t += SEL_THREADS) se += expf(zbuf[t] - zmax);
+    for (int t = tid; t < T; t += SEL_THREADS) se += expf((LONG ? zf(t) : zbuf[t]) - zmax);
     se = block_sum(se, red);
     __syncthreads();  // idx writes of this block visible to the block (global, same workgroup)
     const int64_t* my = idx + ((size_t)b * G + g) * k;
     for (int t = tid; t < T; t += SEL_THREADS) {
-      const float y = expf(zbuf[t] - zmax) / se;
+      const float y = expf((LONG ? zf(t) : zbuf[t]) - zmax) / se;
       int lo = 0, hi = k - 1;
       float oh = 0.f;
       while (lo <= hi) {
@@ -303,14 +312,18 @@ extern "C" int tspo_gumbel_topk(const float* logits, const float* noise, uint64_
   TSPO_REQUIRE(logits && idx, "gumbel_topk: null pointer");
   TSPO_REQUIRE(B >= 0 && G >= 1 && T >= 1 && k >= 1, "gumbel_topk: bad dims B=%d G=%d T=%d k=%d", B, G, T, k);
   TSPO_REQUIRE(k <= T, "gumbel_topk: selected index k out of range (k=%d > T=%d)", k, T);
-  TSPO_REQUIRE(T <= SEL_LDS_KEYS, "gumbel_topk: T=%d exceeds the LDS-resident limit %d", T, SEL_LDS_KEYS);
   TSPO_REQUIRE(tau > 0.f, "gumbel_topk: tau must be > 0");
   if (B == 0) return TSPO_OK;
   const uint32_t key0 = (uint32_t)(seed & 0xFFFFFFFFu);
   const uint32_t key1 = (uint32_t)(((seed >> 32) ^ (offset >> 32)) & 0xFFFFFFFFu);
-  const size_t lds = (size_t)T * 4 * (probs ? 2 : 1);
-  hipLaunchKernelGGL(gumbel_topk_kernel, dim3(G, B), dim3(SEL_THREADS), lds, (hipStream_t)stream, logits, noise, key0,
-                     key1, (uint32_t)(offset & 0xFFFFFFFFu), G, T, k, tau, idx, logp, probs, noise_out);
+  if (T <= SEL_LDS_KEYS) {
+    const size_t lds = (size_t)T * 4 * (probs ? 2 : 1);
+    hipLaunchKernelGGL(gumbel_topk_kernel<false>, dim3(G, B), dim3(SEL_THREADS), lds, (hipStream_t)stream, logits, noise, key0,
+                       key1, (uint32_t)(offset & 0xFFFFFFFFu), G, T, k, tau, idx, logp, probs, noise_out);
+  } else {
+    hipLaunchKernelGGL(gumbel_topk_kernel<true>, dim3(G, B), dim3(SEL_THREADS), 0, (hipStream_t)stream, logits, noise, key0,
+                       key1, (uint32_t)(offset & 0xFFFFFFFFu), G, T, k, tau, idx, logp, probs, noise_out);
+  }
   return tspo::check_launch("gumbel_topk");
 }
 
@@ -570,30 +583,48 @@ __global__ __launch_bounds__(256) void sqsum_partial4_kernel(const float* __rest
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-extern "C" int tspo_adamw_clip_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1,
-                                    float beta2, float eps, float weight_decay, int step, float pre_scale, float max_norm,
-                                    float* out2, void* workspace, size_t workspace_bytes, tspo_stream_t stream) {
-  TSPO_REQUIRE(param && grad && m && v && out2 && workspace, "adamw_clip_step: null pointer");
+static int adamw_clip_impl(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, float pre_scale, float max_norm,
+                           float* out2, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
+                           const float* norm_partials, int n_partials) {
+  TSPO_REQUIRE(param && grad && m && v && out2 && (workspace || norm_partials), "adamw_clip_step: null pointer");
+  TSPO_REQUIRE(!norm_partials || (n_partials >= 1 && n_partials <= NORM_BLOCKS), "adamw_clip_step_ex: n_partials=%d (1..%d)",
+               n_partials, NORM_BLOCKS);
   TSPO_REQUIRE(step >= 1, "adamw_clip_step: step must be >= 1");
   TSPO_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                "adamw_clip_step: buffers must be 16-byte aligned");
-  if (workspace_bytes < NORM_BLOCKS * sizeof(float))
+  if (!norm_partials && workspace_bytes < NORM_BLOCKS * sizeof(float))
     return tspo::set_err(TSPO_EWORKSPACE, "adamw_clip_step: workspace %zu < %zu", workspace_bytes,
                          NORM_BLOCKS * sizeof(float));
   if (n == 0) return TSPO_OK;
   int nb = (int)((n / 4 + 255) / 256);
   if (nb > NORM_BLOCKS) nb = NORM_BLOCKS;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(sqsum_partial4_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grad, n, (float*)workspace);
+  if (norm_partials) nb = n_partials;     // the producer of the gradient already left its partial sums of squares
+  else hipLaunchKernelGGL(sqsum_partial4_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, grad, n, (float*)workspace);
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   size_t ab = (n / 4 + 255) / 256;
   if (ab > 2048) ab = 2048;
   if (ab < 1) ab = 1;
   hipLaunchKernelGGL(adamw_clip_kernel, dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), (const float*)workspace, nb, pre_scale,
-                     max_norm, out2);
+                     beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)),
+                     norm_partials ? norm_partials : (const float*)workspace, nb, pre_scale, max_norm, out2);
   return tspo::check_launch("adamw_clip_step");
+}
+
+extern "C" int tspo_adamw_clip_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, float pre_scale, float max_norm,
+                                    float* out2, void* workspace, size_t workspace_bytes, tspo_stream_t stream) {
+  return adamw_clip_impl(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, step, pre_scale, max_norm, out2, workspace,
+                         workspace_bytes, stream, nullptr, 0);
+}
+extern "C" int tspo_adamw_clip_step_ex(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, int step, float pre_scale, float max_norm,
+                                       float* out2, const float* norm_partials, int n_partials, tspo_stream_t stream) {
+  TSPO_REQUIRE(norm_partials, "adamw_clip_step_ex: null norm_partials");
+  return adamw_clip_impl(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, step, pre_scale, max_norm, out2, nullptr, 0,
+                         stream, norm_partials, n_partials);
 }
 
 extern "C" int tspo_adamw_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1,

@@ -36,14 +36,21 @@ namespace {
 // (model/temporal_agent.py:10-19, 128-129); all fp32 like torch.
 __global__ __launch_bounds__(256) void posenc_add_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                          int T, int D, size_t total) {
+  // one thread per (row, channel pair): the pair (2i, 2i+1) shares its angle - one expf and one sincosf for two outputs
+  // (same values as separate sinf / cosf calls), 8-byte loads and stores.  D is even (D % 64 == 0).
   const float c = -9.21034049987793f / (float)D;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int d = (int)(i % D);
-    const int t = (int)((i / D) % T);
-    const float div = expf((float)(d & ~1) * c);
+  const size_t pairs = total >> 1;
+  const int hd = D >> 1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (size_t)gridDim.x * 256) {
+    const int pi = (int)(i % hd);
+    const int t = (int)((i / hd) % T);
+    const float div = expf((float)(2 * pi) * c);
     const float pos = (float)t / (float)T;
     const float a = pos * div;
-    out[i] = x[i] + ((d & 1) ? cosf(a) : sinf(a));
+    float sn, cs;
+    sincosf(a, &sn, &cs);
+    const float2 v = reinterpret_cast<const float2*>(x)[i];
+    reinterpret_cast<float2*>(out)[i] = make_float2(v.x + sn, v.y + cs);
   }
 }
 
@@ -1242,7 +1249,11 @@ struct RedSegs {
   int S[RED_SEGS];
   int count;
 };
-__global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L) {   // every n is a multiple of 4 (D % 64 == 0)
+// norm_partial != nullptr: block b also writes the sum of squares of the values it produced to norm_partial[b] (the
+// optimiser's gradient norm without a second pass over the bucket; fixed grid -> fixed order -> deterministic).
+__global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L, float* __restrict__ norm_partial) {   // every n is a multiple of 4 (D % 64 == 0)
+  __shared__ float red[32];
+  float sq = 0.f;
   const unsigned long long total4 = L.end[L.count - 1] >> 2;
   for (unsigned long long i4 = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i4 < total4;
        i4 += (unsigned long long)gridDim.x * 256) {
@@ -1256,6 +1267,11 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L) {   // 
     const size_t stride = L.n[g];
     for (int s = 0; s < S; ++s) a += *reinterpret_cast<const f32x4*>(p + (size_t)s * stride);
     *reinterpret_cast<f32x4*>(L.out[g] + e) = a;
+    sq += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+  }
+  if (norm_partial) {
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) norm_partial[blockIdx.x] = sq;
   }
 }
 
@@ -1387,8 +1403,8 @@ static int selector_forward_impl(const tspo_selector_weights* w, const float* im
   hipStream_t st = (hipStream_t)stream;
   const int BT = B * T;
   const size_t tot = (size_t)BT * D;
-  int nb = (int)((tot + 255) / 256);
-  if (nb > 2048) nb = 2048;
+  int nb = (int)((tot / 2 + 255) / 256);
+  if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(posenc_add_kernel, dim3(nb), dim3(256), 0, st, img, s.xpe, T, D, tot);
   if (int e = launch_gemm_nt<EPI_NONE>(s.xpe, w->wqkv, w->bqkv, nullptr, s.qkv, BT, 3 * D, D, st, split)) return e;
   const long pairs = (long)BT * H;
@@ -1451,7 +1467,8 @@ int dgrad_with_wgrad(const float* dY, const float* Wt, const float* R, float* dX
 static int selector_backward_impl(const tspo_selector_weights* w, const float* img, const float* txt,
                                   const float* dscores, int B, int T, int D, int H, int M, int window, float tau,
                                   const tspo_selector_grads* g, void* workspace, size_t workspace_bytes,
-                                  tspo_stream_t stream, int flags, const PgIn* pg = nullptr) {
+                                  tspo_stream_t stream, int flags, const PgIn* pg = nullptr, float* norm_partials = nullptr,
+                                  int* n_partials = nullptr) {
   const bool split = (flags & TSPO_SEL_BF16X3) != 0;
   TSPO_REQUIRE((flags & ~TSPO_SEL_BF16X3) == 0, "selector_backward: unknown flags 0x%x", flags);
   TSPO_REQUIRE(w && img && txt && (dscores || pg) && g && workspace, "selector_backward: null pointer");
@@ -1530,7 +1547,11 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
   L.count = RED_SEGS;
   int nb = (int)((run / 4 + 255) / 256);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L);
+  if (norm_partials) {   // one partial sum of squares per block, at most the 512 tspo_adamw_clip_step_ex accepts
+    if (nb > 512) nb = 512;
+    if (n_partials) *n_partials = nb;
+  }
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L, norm_partials);
   (void)img;
   return tspo::check_launch("selector_backward");
 }
@@ -1545,6 +1566,19 @@ extern "C" int tspo_policy_backward(const tspo_selector_weights* w, const float*
   const PgIn pg{rewards, logp, idx, G, k, adv_eps, scale, adv, loss};
   return selector_backward_impl(w, img, txt, nullptr, B, T, D, H, M, window, tau, grads, workspace, workspace_bytes, stream,
                                 flags, &pg);
+}
+
+extern "C" int tspo_policy_backward_ex(const tspo_selector_weights* w, const float* img, const float* txt, const float* rewards,
+                                       const float* logp, const int64_t* idx, int B, int T, int D, int H, int M, int window,
+                                       float tau, int G, int k, float adv_eps, float scale, const tspo_selector_grads* grads,
+                                       float* adv, float* loss, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
+                                       int flags, float* norm_partials, int* n_partials) {
+  TSPO_REQUIRE(rewards && logp && idx && adv, "policy_backward: null pointer");
+  TSPO_REQUIRE(G >= 1 && G <= 64 && k >= 1 && k <= T, "policy_backward: bad dims G=%d (1..64) k=%d T=%d", G, k, T);
+  TSPO_REQUIRE(!norm_partials || n_partials, "policy_backward_ex: norm_partials without n_partials");
+  const PgIn pg{rewards, logp, idx, G, k, adv_eps, scale, adv, loss};
+  return selector_backward_impl(w, img, txt, nullptr, B, T, D, H, M, window, tau, grads, workspace, workspace_bytes, stream,
+                                flags, &pg, norm_partials, n_partials);
 }
 
 extern "C" int tspo_selector_backward(const tspo_selector_weights* w, const float* img, const float* txt,

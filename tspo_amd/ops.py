@@ -247,9 +247,11 @@ def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dsc
 
 
 def policy_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, rewards, logp, idx, H, window, tau, ws,
-                    scale: float = 1.0, eps: float = 1e-4, precision: str = "fp32"):
+                    scale: float = 1.0, eps: float = 1e-4, precision: str = "fp32", norm_partials: Optional[torch.Tensor] = None):
     """grpo_pg_grad + selector_backward with one launch less (the score-gradient kernel derives dL/dscores from the
-    rollouts itself): -> (adv [B,G], loss [B]); gradients go to `flat_grad` (equal to the two-call form to rounding)."""
+    rollouts itself): -> (adv [B,G], loss [B]); gradients go to `flat_grad` (equal to the two-call form to rounding).
+    norm_partials (f32 [>=512]): the backward's last kernel also leaves the gradient's partial sums of squares there
+    and the call returns (adv, loss, n_partials) - feed them to adamw_clip_step(norm_partials=...) (one launch)."""
     _need_gpu(flat, flat_grad, img, txt, rewards, logp, idx, ws)
     x, e, r, lp = _f32c(img), _f32c(txt), _f32c(rewards), _f32c(logp)
     ix = idx.to(torch.int64).contiguous()
@@ -263,6 +265,16 @@ def policy_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, rewar
     g = _sel_structs(flat_grad, D, _lib.SelectorGrads)
     adv = torch.empty_like(r)
     loss = torch.empty((B,), dtype=torch.float32, device=x.device)
+    if norm_partials is not None:
+        _need_gpu(norm_partials)
+        if norm_partials.dtype != torch.float32 or norm_partials.numel() < 512:
+            raise ValueError("norm_partials must be a float32 tensor of >= 512 elements")
+        npart = C.c_int(0)
+        check(_lib.lib().tspo_policy_backward_ex(C.byref(w), _ptr(x), _ptr(e), _ptr(r), _ptr(lp), _ptr(ix), B, T, D, H, M,
+                                                 int(window), float(tau), G, k, float(eps), float(scale), C.byref(g), _ptr(adv),
+                                                 _ptr(loss), _ptr(ws), ws.numel(), _stream(), _sel_flags(precision),
+                                                 _ptr(norm_partials), C.byref(npart)), "tspo_policy_backward_ex")
+        return adv, loss, int(npart.value)
     check(_lib.lib().tspo_policy_backward(C.byref(w), _ptr(x), _ptr(e), _ptr(r), _ptr(lp), _ptr(ix), B, T, D, H, M, int(window),
                                           float(tau), G, k, float(eps), float(scale), C.byref(g), _ptr(adv), _ptr(loss), _ptr(ws),
                                           ws.numel(), _stream(), _sel_flags(precision)), "tspo_policy_backward")
@@ -293,11 +305,19 @@ def adamw_step(param, grad, m, v, n: int, lr: float, step: int, beta1=0.9, beta2
 
 def adamw_clip_step(param, grad, m, v, n: int, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
                     pre_scale: float = 1.0, max_norm: float = 1.0, out: Optional[torch.Tensor] = None,
-                    ws: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """grad_norm_scale + adamw_step (two launches instead of three) -> device tensor [2] = (||g||, applied scale)."""
-    _need_gpu(param, grad, m, v, out, ws)
+                    ws: Optional[torch.Tensor] = None, norm_partials: Optional[torch.Tensor] = None,
+                    n_partials: int = 0) -> torch.Tensor:
+    """grad_norm_scale + adamw_step (two launches instead of three) -> device tensor [2] = (||g||, applied scale).
+    With norm_partials / n_partials from policy_backward(norm_partials=...): one launch."""
+    _need_gpu(param, grad, m, v, out, ws, norm_partials)
     if out is None:
         out = torch.empty((2,), dtype=torch.float32, device=grad.device)
+    if norm_partials is not None:
+        check(_lib.lib().tspo_adamw_clip_step_ex(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, float(lr), float(beta1),
+                                                 float(beta2), float(eps), float(weight_decay), int(step), float(pre_scale),
+                                                 float(max_norm), _ptr(out), _ptr(norm_partials), int(n_partials), _stream()),
+              "tspo_adamw_clip_step_ex")
+        return out
     if ws is None:
         ws = torch.empty((2048,), dtype=torch.uint8, device=grad.device)
     check(_lib.lib().tspo_adamw_clip_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, float(lr), float(beta1),

@@ -105,10 +105,12 @@ class PolicyTrainer:
         self.n_train = ops.trainable_numel(dim)
         self.seed, self.step_no = seed, 0       # step_no = optimizer steps taken (AdamW bias correction)
         self.pg = process_group
+        self._default_reduce = reduce_fn is None
         if reduce_fn is None:
             from .dist import allreduce_bucket_
             reduce_fn = allreduce_bucket_
         self.reduce_fn = reduce_fn              # (bucket, n, group) -> world size; leaves the SUM over ranks in bucket[:n]
+        self._reduce_default = reduce_fn
         self.grad_accum_steps = int(grad_accum_steps)
         assert self.grad_accum_steps >= 1
         self._micro = 0                         # micro-steps accumulated since the last optimizer step
@@ -118,6 +120,8 @@ class PolicyTrainer:
         self._gmicro = None                     # scratch bucket of the 2nd.. micro-step's gradient
         self._norm_out = torch.empty((2,), dtype=torch.float32, device=flat.device)
         self._norm_ws = torch.empty((2048,), dtype=torch.uint8, device=flat.device)
+        self._norm_part = torch.empty((512,), dtype=torch.float32, device=flat.device)
+        self._norm_np = 0                       # > 0: the last backward left the bucket's partial sums of squares there
         self._rank = rank
 
     # ---- topology -----------------------------------------------------------------------------------------
@@ -130,6 +134,11 @@ class PolicyTrainer:
             return self._rank
         import torch.distributed as dist
         return dist.get_rank(self.pg) if (dist.is_available() and dist.is_initialized()) else 0
+
+    @staticmethod
+    def _dist_initialised() -> bool:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
 
     def _rank_seed(self) -> int:
         """Philox key of this rank: every data-parallel rank must draw DIFFERENT Gumbel noise for its prompts (the
@@ -178,7 +187,16 @@ class PolicyTrainer:
                 self._gmicro = torch.empty_like(self.grad)
             target = self._gmicro
         scale = 1.0 / (B * self.grad_accum_steps)
-        if idx.shape[1] <= 64:      # advantage -> dL/dscores inside the backward's first kernel (one launch less)
+        self._norm_np = 0
+        # single rank, no accumulation, default exchange: nothing touches the bucket between this backward and AdamW, so the
+        # backward's last kernel (the split reduction that writes the bucket) also leaves its sum of squares
+        fuse_norm = (self.grad_accum_steps == 1 and self._default_reduce and self.reduce_fn is self._reduce_default
+                     and self.world() == 1 and not self._dist_initialised())
+        if idx.shape[1] <= 64 and fuse_norm:
+            adv, loss, self._norm_np = ops.policy_backward(self.flat, target, feats, txt, rewards, logp, idx, self.heads,
+                                                           self.window, ctx.tau, ctx.ws, scale=scale,
+                                                           precision=self.gemm_precision, norm_partials=self._norm_part)
+        elif idx.shape[1] <= 64:    # advantage -> dL/dscores inside the backward's first kernel (one launch less)
             adv, loss = ops.policy_backward(self.flat, target, feats, txt, rewards, logp, idx, self.heads, self.window, ctx.tau,
                                             ctx.ws, scale=scale, precision=self.gemm_precision)
         else:
@@ -210,9 +228,12 @@ class PolicyTrainer:
         # mean at max_norm == clipping the sum at world*max_norm, then scaling by 1/world (no extra pass over the bucket)
         use_lr = lr if lr is not None else self.current_lr()
         self.step_no += 1
+        fused = self._norm_np > 0 and world == 1 and self.reduce_fn is self._reduce_default
         ns = ops.adamw_clip_step(self.flat, self.grad, self.m, self.v, self.n_train, use_lr, self.step_no, self.betas[0],
                                  self.betas[1], self.eps, self.wd, pre_scale=1.0 / world, max_norm=self.max_norm * world,
-                                 out=self._norm_out, ws=self._norm_ws)
+                                 out=self._norm_out, ws=self._norm_ws, norm_partials=self._norm_part if fused else None,
+                                 n_partials=self._norm_np if fused else 0)
+        self._norm_np = 0
         self._micro = 0
         self._param_version += 1
         return {"grad_norm_scale": ns, "lr": use_lr, "world": world}
