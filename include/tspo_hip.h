@@ -188,8 +188,8 @@ int tspo_policy_backward(const tspo_selector_weights* w, const float* img, const
                          void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags);
 
 /* tspo_policy_backward that also leaves the sum of squares of the gradient it
- * wrote (all six trainable tensors) as *n_partials <= 512 block partials in
- * norm_partials (f32, >= 512 floats), for tspo_adamw_clip_step_ex: the
+ * wrote (all six trainable tensors) as *n_partials <= 2048 block partials in
+ * norm_partials (f32, >= 2048 floats), for tspo_adamw_clip_step_ex: the
  * clip_grad_norm_ of the HF Trainer (tspo_trainer.py via Trainer.training_step)
  * then costs no pass of its own.  Only valid while the gradient bucket is not
  * modified between the two calls (single rank, no gradient accumulation);

@@ -337,6 +337,60 @@ def gen_glue(_out):
                       "written_relpath": os.path.join("jsons_idx", f"run7_{data}_frameIdx.json"), "written_text": out_text,
                       "printed_missing": r.stdout.split()})
     g["frame_idx_join"] = joins
+
+    # ---- frame plans of the harness (lmms-eval llava_vid_tspo.py:315-380): the reference's own method bodies, taken from the
+    #      class by AST, run against a fake decord reader ----
+    import ast as _ast
+    src = open("/root/reference/lmms-eval/lmms_eval/models/simple/llava_vid_tspo.py").read()
+    cls = [n for n in _ast.parse(src).body if isinstance(n, _ast.ClassDef)]
+    meths = [m for c in cls for m in c.body if isinstance(m, _ast.FunctionDef) and m.name in ("load_video", "load_video_sampled",
+                                                                                             "load_video_index")]
+    assert sorted(m.name for m in meths) == ["load_video", "load_video_index", "load_video_sampled"]
+
+    class _Batch:
+        def __init__(self, idx):
+            self.idx = idx
+
+        def asnumpy(self):
+            return np.asarray([float(i) for i in self.idx])
+
+    class _Reader:
+        def __init__(self, path, ctx=None, num_threads=1):
+            self.n, self.fps = path
+
+        def __len__(self):
+            return self.n
+
+        def get_avg_fps(self):
+            return self.fps
+
+        def get_batch(self, idx):
+            return _Batch(idx)
+
+    ns3 = {"np": np, "VideoReader": _Reader, "cpu": lambda i: None}
+    exec(compile(_ast.Module(body=meths, type_ignores=[]), "llava_vid_tspo.py", "exec"), ns3)
+    plans = []
+    for total, avg_fps, fps, mx in [(9000, 30.0, 1, 64), (1500, 29.97, 1, 64), (900, 25.0, 1, 64), (9000, 30.0, 2, 32),
+                                    (50, 30.0, 1, 8), (100000, 23.976, 1, 64)]:
+        fr, ft, vt = ns3["load_video"](None, (total, avg_fps), mx, fps)
+        fr2, ft2, vt2 = ns3["load_video"](None, (total, avg_fps), mx, fps, force_sample=True)
+        step = round(avg_fps / fps)
+        n_cand = len(range(0, total, step))
+        pick = sorted(int(v) for v in np.argsort(synth.uniform((n_cand,), 900 + total))[:mx]) if n_cand > mx else None
+        agent = lambda proc, cand, problem, sample_num, window_size, method, processor_type: (torch.tensor(pick), None)
+        fs, fts, vts = ns3["load_video_sampled"](None, (total, avg_fps), mx, fps, "q", agent, None)
+        docs = [[float(step * v) for v in np.sort(np.argsort(synth.uniform((n_cand,), 950 + total))[:mx])][::-1],   # unsorted on purpose
+                [float(step * v) for v in range(min(5, n_cand))]]                                                   # too short -> uniform
+        idx_plans = []
+        for d in docs:
+            fi, fti, vti = ns3["load_video_index"](None, (total, avg_fps), mx, fps, {"frame_idx": d})
+            idx_plans.append({"doc_frame_idx": d, "frames": fi.tolist(), "frame_time": fti, "video_time": vti})
+        plans.append({"total": total, "avg_fps": avg_fps, "fps": fps, "max_frames_num": mx,
+                      "uniform": {"frames": fr.tolist(), "frame_time": ft, "video_time": vt},
+                      "uniform_forced": {"frames": fr2.tolist(), "frame_time": ft2, "video_time": vt2},
+                      "sampled": {"pick": pick, "frames": fs.tolist(), "frame_time": fts, "video_time": vts},
+                      "from_index": idx_plans})
+    g["frame_plans"] = plans
     path = os.path.join(HERE, "glue.json")
     with open(path, "w") as f:
         json.dump(g, f, indent=0)

@@ -92,7 +92,7 @@ def test_gumbel_topk_long_rows_beyond_lds():
     that is extended past the limit with -inf logits."""
     B, G, T, k = 2, 3, 20000, 48
     logits = synth.normal((B, T), 91, 3.0)
-    u = np.clip(synth.uniform((B, G, T), 92), 1e-6, 1 - 1e-6)
+    u = np.clip(synth.uniform((B, G, T), 92).reshape(B, G, T), 1e-6, 1 - 1e-6)
     noise = (-np.log(-np.log(u))).astype(np.float32)
     out = ops.gumbel_topk(G_(logits), k, G, noise=G_(noise), want_probs=True)
     for b in range(B):

@@ -114,6 +114,8 @@ int main() {
   for (int valu : {0, 8, 24}) {
     runhot("16 rows x 64 B", store_kernel<0, false>, valu);
     runhot("8 rows x 128 B", store_kernel<1, false>, valu);
+    runhot("16 rows x 64 B, nontemporal", store_kernel<0, true>, valu);
+    runhot("8 rows x 128 B, nontemporal", store_kernel<1, true>, valu);
   }
   {
     uint32_t* sink; hipMalloc(&sink, 64);

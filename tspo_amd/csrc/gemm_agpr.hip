@@ -426,6 +426,11 @@ int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
   }
   if (g.variant == 95) return launch_gemm_a7<EPI, false, true, false, 8>(g, st);    // timing only: W addressed as 1 KB blocks
   if (g.variant == 96) return launch_gemm_a7<EPI, false, true, false, 24>(g, st);   // timing only: W and A addressed as 1 KB blocks
+  if (g.variant == 97 || g.variant == 98 || g.variant == 99) {   // N groups per XCD set: 1 / 4 / 8 (shipped: 2 for wide N)
+    GemmArgs h = g;
+    h.ngrp = g.variant == 97 ? 1 : (g.variant == 98 ? 4 : 8);
+    return launch_gemm_a7<EPI, false, true>(h, st);
+  }
   if (g.variant == 86) { GemmArgs h = g; h.P = -1; return launch_gemm_a7<EPI, false, true>(h, st); }   // epilogue without memory traffic
   if (g.variant == 87) { GemmArgs h = g; h.P = -2; return launch_gemm_a7<EPI, false, true>(h, st); }   // epilogue to / from one hot tile per workgroup
 #endif

@@ -179,29 +179,40 @@ __global__ __launch_bounds__(256) void resample_h_lds_kernel(const uint8_t* __re
   }
 }
 
-// four adjacent output columns per thread (ow % 4 == 0, buffers dword-aligned)
+// vertical pass: four adjacent output columns per thread (ow % 4 == 0, buffers dword-aligned), one output ROW per wave, so
+// the row's taps and bounds are wave-uniform: staged in LDS once per workgroup (4 rows) and read back as broadcasts; the
+// only per-lane memory traffic left is one coalesced dword load of the uint8 intermediate per tap
 __global__ __launch_bounds__(256) void resample_v4_kernel(const uint8_t* __restrict__ tmp, int T, int nrows, int ow,
                                                           const int* __restrict__ coef, const int* __restrict__ bound,
                                                           int oh, int ksize, int ylo, uint8_t* __restrict__ out) {
-  const int ow4 = ow >> 2;
-  const size_t total = (size_t)T * 3 * oh * ow4;
-  for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (size_t)gridDim.x * 256) {
-    const int x = (int)(id % ow4) * 4;
-    const int y = (int)((id / ow4) % oh);
-    const size_t tc = id / ((size_t)ow4 * oh);
-    const int ymin = bound[2 * y] - ylo, yn = bound[2 * y + 1];
-    const int* k = coef + (size_t)y * ksize;
-    const uint8_t* p = tmp + (tc * nrows + ymin) * (size_t)ow + x;
-    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21, a3 = 1 << 21;
-    for (int i = 0; i < yn; ++i) {
-      const uint32_t u = *reinterpret_cast<const uint32_t*>(p + (size_t)i * ow);
-      const int w = k[i];
-      a0 += __mul24(w, (int)(u & 255u)); a1 += __mul24(w, (int)((u >> 8) & 255u)); a2 += __mul24(w, (int)((u >> 16) & 255u));
-      a3 += __mul24(w, (int)(u >> 24));
-    }
-    *reinterpret_cast<uint32_t*>(out + (tc * oh + y) * (size_t)ow + x) =
-        (uint32_t)clip8(a0) | ((uint32_t)clip8(a1) << 8) | ((uint32_t)clip8(a2) << 16) | ((uint32_t)clip8(a3) << 24);
+  extern __shared__ int pv_lds[];   // [4][ksize] taps, then [4][2] bounds
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ow4 = ow >> 2, xblocks = (ow4 + 63) >> 6, ygroups = (oh + 3) >> 2;
+  const int xb = blockIdx.x % xblocks, yg = (blockIdx.x / xblocks) % ygroups;
+  const size_t tc = blockIdx.x / ((size_t)xblocks * ygroups);
+  int* bl = pv_lds + 4 * ksize;
+  for (int idx = tid; idx < 4 * ksize; idx += 256) {
+    const int yy = yg * 4 + idx / ksize;
+    pv_lds[idx] = yy < oh ? coef[(size_t)yy * ksize + idx % ksize] : 0;
   }
+  if (tid < 8) { const int yy = yg * 4 + (tid >> 1); bl[tid] = yy < oh ? bound[2 * yy + (tid & 1)] : 0; }
+  __syncthreads();
+  const int y = yg * 4 + wv, x4 = xb * 64 + lane;
+  if (y >= oh || x4 >= ow4) return;
+  const int ymin = bl[2 * wv] - ylo, yn = bl[2 * wv + 1];
+  const int* k = pv_lds + wv * ksize;
+  const uint8_t* p = tmp + (tc * nrows + ymin) * (size_t)ow + (size_t)x4 * 4;
+  int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21, a3 = 1 << 21;
+#pragma unroll 4
+  for (int i = 0; i < yn; ++i) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p + (size_t)i * ow);
+    const int w = k[i];
+    a0 += __mul24(w, (int)(u & 255u)); a1 += __mul24(w, (int)((u >> 8) & 255u)); a2 += __mul24(w, (int)((u >> 16) & 255u));
+    a3 += __mul24(w, (int)(u >> 24));
+  }
+  *reinterpret_cast<uint32_t*>(out + (tc * oh + y) * (size_t)ow + (size_t)x4 * 4) =
+      (uint32_t)clip8(a0) | ((uint32_t)clip8(a1) << 8) | ((uint32_t)clip8(a2) << 16) | ((uint32_t)clip8(a3) << 24);
 }
 
 }  // namespace
@@ -247,10 +258,9 @@ extern "C" int tspo_preprocess_frames(const uint8_t* frames, int layout, int T, 
     else
       hipLaunchKernelGGL(resample_h_lds_kernel<1>, dim3(grid), dim3(256), lds_bytes, st, frames, in_bytes, T, H, W, hcoef, hbound,
                          out_w, hk, ylo, nrows, nrb, nchunk, pitch, (uint8_t*)workspace);
-    const size_t n4 = n2 / 4;
-    const unsigned g4 = (unsigned)((n4 + 255) / 256 > 65536 ? 65536 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(resample_v4_kernel, dim3(g4), dim3(256), 0, st, (const uint8_t*)workspace, T, nrows, out_w, vcoef,
-                       vbound, out_h, vk, ylo, out);
+    const size_t g4 = (size_t)T * 3 * ((out_h + 3) / 4) * ((out_w / 4 + 63) / 64);
+    hipLaunchKernelGGL(resample_v4_kernel, dim3((unsigned)g4), dim3(256), (size_t)(4 * vk + 8) * 4, st, (const uint8_t*)workspace, T,
+                       nrows, out_w, vcoef, vbound, out_h, vk, ylo, out);
     return tspo::check_launch("preprocess_frames");
   }
   hipLaunchKernelGGL(resample_h_kernel, dim3(g1), dim3(256), 0, st, frames, layout, T, H, W, hcoef, hbound, out_w, hk, ylo,

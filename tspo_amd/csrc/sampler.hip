@@ -588,8 +588,8 @@ static int adamw_clip_impl(float* param, const float* grad, float* m, float* v, 
                            float* out2, void* workspace, size_t workspace_bytes, tspo_stream_t stream,
                            const float* norm_partials, int n_partials) {
   TSPO_REQUIRE(param && grad && m && v && out2 && (workspace || norm_partials), "adamw_clip_step: null pointer");
-  TSPO_REQUIRE(!norm_partials || (n_partials >= 1 && n_partials <= NORM_BLOCKS), "adamw_clip_step_ex: n_partials=%d (1..%d)",
-               n_partials, NORM_BLOCKS);
+  TSPO_REQUIRE(!norm_partials || (n_partials >= 1 && n_partials <= 4 * NORM_BLOCKS), "adamw_clip_step_ex: n_partials=%d (1..%d)",
+               n_partials, 4 * NORM_BLOCKS);
   TSPO_REQUIRE(step >= 1, "adamw_clip_step: step must be >= 1");
   TSPO_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                "adamw_clip_step: buffers must be 16-byte aligned");

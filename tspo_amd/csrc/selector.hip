@@ -1547,8 +1547,8 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
   L.count = RED_SEGS;
   int nb = (int)((run / 4 + 255) / 256);
   if (nb > 4096) nb = 4096;
-  if (norm_partials) {   // one partial sum of squares per block, at most the 512 tspo_adamw_clip_step_ex accepts
-    if (nb > 512) nb = 512;
+  if (norm_partials) {   // one partial sum of squares per block, at most the 2048 tspo_adamw_clip_step_ex accepts
+    if (nb > 2048) nb = 2048;
     if (n_partials) *n_partials = nb;
   }
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L, norm_partials);

@@ -250,7 +250,7 @@ def policy_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, rewar
                     scale: float = 1.0, eps: float = 1e-4, precision: str = "fp32", norm_partials: Optional[torch.Tensor] = None):
     """grpo_pg_grad + selector_backward with one launch less (the score-gradient kernel derives dL/dscores from the
     rollouts itself): -> (adv [B,G], loss [B]); gradients go to `flat_grad` (equal to the two-call form to rounding).
-    norm_partials (f32 [>=512]): the backward's last kernel also leaves the gradient's partial sums of squares there
+    norm_partials (f32 [>=2048]): the backward's last kernel also leaves the gradient's partial sums of squares there
     and the call returns (adv, loss, n_partials) - feed them to adamw_clip_step(norm_partials=...) (one launch)."""
     _need_gpu(flat, flat_grad, img, txt, rewards, logp, idx, ws)
     x, e, r, lp = _f32c(img), _f32c(txt), _f32c(rewards), _f32c(logp)
@@ -267,8 +267,8 @@ def policy_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, rewar
     loss = torch.empty((B,), dtype=torch.float32, device=x.device)
     if norm_partials is not None:
         _need_gpu(norm_partials)
-        if norm_partials.dtype != torch.float32 or norm_partials.numel() < 512:
-            raise ValueError("norm_partials must be a float32 tensor of >= 512 elements")
+        if norm_partials.dtype != torch.float32 or norm_partials.numel() < 2048:
+            raise ValueError("norm_partials must be a float32 tensor of >= 2048 elements")
         npart = C.c_int(0)
         check(_lib.lib().tspo_policy_backward_ex(C.byref(w), _ptr(x), _ptr(e), _ptr(r), _ptr(lp), _ptr(ix), B, T, D, H, M,
                                                  int(window), float(tau), G, k, float(eps), float(scale), C.byref(g), _ptr(adv),

@@ -120,7 +120,7 @@ class PolicyTrainer:
         self._gmicro = None                     # scratch bucket of the 2nd.. micro-step's gradient
         self._norm_out = torch.empty((2,), dtype=torch.float32, device=flat.device)
         self._norm_ws = torch.empty((2048,), dtype=torch.uint8, device=flat.device)
-        self._norm_part = torch.empty((512,), dtype=torch.float32, device=flat.device)
+        self._norm_part = torch.empty((2048,), dtype=torch.float32, device=flat.device)
         self._norm_np = 0                       # > 0: the last backward left the bucket's partial sums of squares there
         self._rank = rank
 
