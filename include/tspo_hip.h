@@ -319,6 +319,22 @@ int tspo_preprocess_frames(const uint8_t* frames, int layout, int T, int H, int 
                            int ylo, int nrows, uint8_t* out,
                            void* workspace, size_t workspace_bytes, tspo_stream_t stream);
 
+/* Same, with the horizontal pass on the matrix pipe: the taps of every 16-column
+ * block as signed-byte digit matrices (k = d0 + 2^8 d1 + 2^16 d2) laid out
+ * [block][K block of 64 input columns][digit][lane 0..63][16 bytes] (int8),
+ * mfma_bias i32 [out_w] = 128 * sum(taps) + 2^21, mfma_xs i32 [out_w/16] = first
+ * input column of each block, mfma_nkb (1..4) K blocks per block, mfma_span =
+ * widest input span (pixels) of four consecutive blocks.  Bit-identical output;
+ * mfma_taps == NULL or an unsupported geometry (out_w % 16, span too wide for
+ * LDS) takes the scalar kernels.  tspo_amd/preprocess.py builds the tables.  */
+int tspo_preprocess_frames_ex(const uint8_t* frames, int layout, int T, int H, int W,
+                              const int32_t* hcoef, const int32_t* hbound, int out_w, int hk,
+                              const int32_t* vcoef, const int32_t* vbound, int out_h, int vk,
+                              int ylo, int nrows, uint8_t* out,
+                              void* workspace, size_t workspace_bytes, tspo_stream_t stream,
+                              const int8_t* mfma_taps, const int32_t* mfma_bias, const int32_t* mfma_xs,
+                              int mfma_nkb, int mfma_span);
+
 /* torch.nn.CosineSimilarity(dim=-1)(text[b,0,:], feat[b,t,:])  (temporal_agent.py:167).
  * txt f32 [B,M,D] (row 0 of each prompt is used), feat f32 [B,T,D] -> clip f32 [B,T]. */
 int tspo_clip_scores(const float* txt, const float* feat, int B, int T, int D, int M, float* clip,

@@ -75,6 +75,7 @@ SIGNATURES = {
     "tspo_clip_vit_profile": (_i, [C.POINTER(ClipWeights), _p, _i, _i, _p, _p, _sz, _p, C.POINTER(C.c_float), _i]),
     "tspo_preprocess_workspace_bytes": (_sz, [_i, _i, _i]),
     "tspo_preprocess_frames": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "tspo_preprocess_frames_ex": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _sz, _p, _p, _p, _p, _i, _i]),
     "tspo_clip_scores": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "tspo_gemm_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
 }

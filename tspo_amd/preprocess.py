@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 PRECISION_BITS = 32 - 8 - 2
+USE_MATRIX_PASS = True      # horizontal pass on the matrix pipe (tspo_preprocess_frames_ex); False = scalar kernels (tests A/B both)
 
 
 def _bicubic(x: float) -> float:
@@ -80,6 +81,43 @@ def _tables(H: int, W: int, size: int):
     return hk, hb, vk, vb, ylo, yhi - ylo
 
 
+def mfma_h_tables(hk: np.ndarray, hb: np.ndarray):
+    """Tables of the matrix-pipe horizontal pass (tspo_preprocess_frames_ex) from the tap table of the crop window:
+    -> (taps int8 [nblk, nkb, 3, 64, 16], bias int32 [ow], xs int32 [nblk], nkb, span) or None when the window is not a
+    whole number of 16-column blocks.  Block b covers output columns 16b..16b+15 and input columns xs[b] .. xs[b]+64*nkb-1;
+    every 22-bit tap k is split into signed byte digits k = d0 + 256 d1 + 65536 d2 (|k| < 2^23, so d2 fits a byte too);
+    lane l = q*16 + x of a fragment holds the 16 bytes of output column x for input columns q*16..q*16+15 of the K block."""
+    ow, ksize = hk.shape
+    if ow % 16 or ksize < 2:
+        return None
+    nblk = ow // 16
+    xs = hb[::16, 0].astype(np.int64)
+    last = hb[15::16]
+    spans = last[:, 0] + last[:, 1] - xs
+    nkb = int((spans.max() + 63) // 64)
+    if nkb < 1 or nkb > 4:
+        return None
+    taps = np.zeros((nblk, nkb * 64, 16), np.int64)           # [block][input column within block][output column within block]
+    for x in range(ow):
+        b, xi = divmod(x, 16)
+        o = int(hb[x, 0] - xs[b])
+        taps[b, o:o + int(hb[x, 1]), xi] = hk[x, :int(hb[x, 1])]
+    d0 = ((taps + 128) % 256) - 128
+    t1 = (taps - d0) // 256
+    d1 = ((t1 + 128) % 256) - 128
+    d2 = (t1 - d1) // 256
+    assert np.abs(d2).max() <= 127 and np.array_equal(d0 + 256 * d1 + 65536 * d2, taps)
+    dig = np.stack([d0, d1, d2], 0).astype(np.int8)            # [digit][block][k][x]
+    # -> [block][K block][digit][q][x][16 consecutive k]
+    dig = dig.reshape(3, nblk, nkb, 4, 16, 16)                  # [d][b][kb][q][j][x]
+    frag = np.ascontiguousarray(dig.transpose(1, 2, 0, 3, 5, 4)).reshape(nblk, nkb, 3, 64, 16)
+    bias = (128 * hk.astype(np.int64).sum(1) + (1 << 21)).astype(np.int64)
+    assert bias.max() < 2 ** 31
+    # widest span of a chunk of four consecutive blocks (what one workgroup stages), in pixels
+    span = max(int(xs[min(c + 3, nblk - 1)] + nkb * 64 - xs[c]) for c in range(0, nblk, 4))
+    return frag, bias.astype(np.int32), xs.astype(np.int32), nkb, span
+
+
 _dev_tables = {}
 
 
@@ -98,15 +136,20 @@ def preprocess_frames(frames: torch.Tensor, size: int = 224) -> torch.Tensor:
     key = (H, W, size, fr.device)
     if key not in _dev_tables:
         hk, hb, vk, vb, ylo, nrows = _tables(H, W, size)
-        _dev_tables[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(fr.device) for a in (hk, hb, vk, vb)) + (ylo, nrows)
-    hk, hb, vk, vb, ylo, nrows = _dev_tables[key]
+        mf = mfma_h_tables(hk, hb)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(fr.device)
+        _dev_tables[key] = tuple(dev(a) for a in (hk, hb, vk, vb)) + (ylo, nrows) + \
+            ((dev(mf[0]), dev(mf[1]), dev(mf[2]), mf[3], mf[4]) if mf is not None else (None, None, None, 0, 0))
+    hk, hb, vk, vb, ylo, nrows, mtaps, mbias, mxs, mnkb, mspan = _dev_tables[key]
     out = torch.empty((T, 3, size, size), dtype=torch.uint8, device=fr.device)
     nws = _lib.lib().tspo_preprocess_workspace_bytes(T, nrows, size)
     ws = torch.empty((nws,), dtype=torch.uint8, device=fr.device)
-    _lib.check(_lib.lib().tspo_preprocess_frames(
+    P = lambda t_: None if t_ is None else C.c_void_p(t_.data_ptr())
+    _lib.check(_lib.lib().tspo_preprocess_frames_ex(
         C.c_void_p(fr.data_ptr()), layout, T, H, W, C.c_void_p(hk.data_ptr()), C.c_void_p(hb.data_ptr()), size, hk.shape[1],
         C.c_void_p(vk.data_ptr()), C.c_void_p(vb.data_ptr()), size, vk.shape[1], ylo, nrows, C.c_void_p(out.data_ptr()),
-        C.c_void_p(ws.data_ptr()), ws.numel(), torch.cuda.current_stream().cuda_stream), "tspo_preprocess_frames")
+        C.c_void_p(ws.data_ptr()), ws.numel(), torch.cuda.current_stream().cuda_stream,
+        P(mtaps) if USE_MATRIX_PASS else None, P(mbias), P(mxs), int(mnkb), int(mspan)), "tspo_preprocess_frames_ex")
     return out
 
 
