@@ -207,10 +207,10 @@ def comm_probe(backend: str, world: int, dev, n_bucket: int) -> dict:
     own = False
     try:
         if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ["MASTER_PORT"] = str(tdist.free_port())
+            # own store on a free port: under torch.distributed.run the env:// rendezvous would go to the agent's store
+            store = dist.TCPStore("127.0.0.1", tdist.free_port(), 1, is_master=True, timeout=datetime.timedelta(seconds=60))
             kw = {"device_id": dev} if backend == "nccl" else {}
-            dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), **kw)
+            dist.init_process_group(backend, store=store, rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), **kw)
             own = True
         info["world"] = dist.get_world_size()
         bucket = torch.ones(n_bucket + 8, dtype=torch.float32, device=dev)

@@ -62,6 +62,23 @@ def test_bench_self_spawns_two_ranks_from_a_bare_shell():
     assert "error" not in comm
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's launch form for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`), here with two ranks on the one GPU (gloo), and the N = 1 form under the launcher."""
+    from tspo_amd.dist import free_port
+    for n, extra in ((2, ["--same-device", "--backend", "gloo"]), (1, [])):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+                            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n),
+                            "--frames", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pruned", "--no-720p"] + extra,
+                           env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in _json_lines(r.stdout) if "metric" in l]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = lines[0]
+        assert line["n_gpus"] == n and line["value"] > 0 and line["comm"]["world"] == n and "error" not in line["comm"]
+        assert line["launcher"] == ("torch.distributed.run" if n > 1 else "single process")
+
+
 def _nccl_worker(q):
     import datetime
     import torch.distributed as dist

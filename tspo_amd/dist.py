@@ -35,6 +35,8 @@ def init_from_env(backend: str = "nccl", device: "torch.device | None" = None, f
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
+        if world == 1:      # forced one-rank group: own store (under torch.distributed.run env:// would wait for the agent's)
+            kw["store"] = dist.TCPStore("127.0.0.1", free_port(), 1, is_master=True)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
