@@ -317,59 +317,60 @@ __global__ __launch_bounds__(256) void resample_h_mfma_kernel(const uint8_t* __r
   }
 }
 
-// vertical pass: 4 output rows x 4 adjacent output columns per thread (ow % 4 == 0, buffers dword-aligned).  A wave owns
-// four consecutive output rows: at a down-scale of s their tap ranges overlap by ksize - 3 s input rows, so every dword of
-// the uint8 intermediate is loaded once for all four (2.4x fewer loads at 720p) and feeds 16 multiply-adds.  The taps of
-// the four rows are laid out in LDS against the wave's common input-row range, zero outside a row's own range, so the
-// loop has no branches; tap reads are LDS broadcasts (the rows of a wave are uniform).
+// vertical pass: PV_R output rows x 4 adjacent output columns per thread (ow % 4 == 0, buffers dword-aligned).  A wave owns
+// PV_R = 4 consecutive output rows: at a down-scale of s their tap ranges overlap by ksize - s input rows from one row to
+// the next, so every dword of the uint8 intermediate is loaded once for all four (2.4x fewer loads at 720p) and feeds
+// up to 16 multiply-adds (PV_R = 8 was measured slower: 92 vs 75 us for 256 720p frames - too few workgroups per plane).  The taps of the rows are laid out in LDS against the wave's common input-row range, zero
+// outside a row's own range, so the loop has no branches; tap reads are LDS broadcasts (a wave's rows are uniform).
+#define PV_R 4
 __global__ __launch_bounds__(256) void resample_v4_kernel(const uint8_t* __restrict__ tmp, int T, int nrows, int ow,
                                                           const int* __restrict__ coef, const int* __restrict__ bound,
                                                           int oh, int ksize, int ylo, int vspan, uint8_t* __restrict__ out) {
-  extern __shared__ int pv_lds[];   // [4 waves][4 rows][vspan] taps against the wave's input-row range
+  extern __shared__ int pv_lds[];   // [4 waves][PV_R rows][vspan] taps against the wave's input-row range
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ow4 = ow >> 2, xblocks = (ow4 + 63) >> 6, ygroups = (oh + 15) >> 4;
+  const int ow4 = ow >> 2, xblocks = (ow4 + 63) >> 6, ygroups = (oh + 4 * PV_R - 1) / (4 * PV_R);
   const int xb = blockIdx.x % xblocks, yg = (blockIdx.x / xblocks) % ygroups;
   const size_t tc = blockIdx.x / ((size_t)xblocks * ygroups);
-  for (int idx = tid; idx < 16 * vspan; idx += 256) pv_lds[idx] = 0;
+  for (int idx = tid; idx < 4 * PV_R * vspan; idx += 256) pv_lds[idx] = 0;
   __syncthreads();
   {   // thread -> (row of the workgroup, tap): scatter the row's taps to their offset in its wave's range
-    const int rr = tid >> 4, y = yg * 16 + rr;          // 16 rows x 16 threads
+    const int rr = tid >> 3, y = yg * 4 * PV_R + rr;          // 32 rows x 8 threads
     if (y < oh) {
-      const int y0 = yg * 16 + (rr & ~3);
+      const int y0 = yg * 4 * PV_R + (rr / PV_R) * PV_R;
       const int base = bound[2 * y0], ymin = bound[2 * y], yn = bound[2 * y + 1];
-      for (int ti = tid & 15; ti < yn; ti += 16) {
+      for (int ti = tid & 7; ti < yn; ti += 8) {
         const int o = ymin - base + ti;
         if (o < vspan) pv_lds[rr * vspan + o] = coef[(size_t)y * ksize + ti];
       }
     }
   }
   __syncthreads();
-  const int y0 = yg * 16 + wv * 4, x4 = xb * 64 + lane;
+  const int y0 = yg * 4 * PV_R + wv * PV_R, x4 = xb * 64 + lane;
   if (y0 >= oh || x4 >= ow4) return;
-  const int ylast = y0 + 3 < oh ? y0 + 3 : oh - 1;
+  const int ylast = y0 + PV_R - 1 < oh ? y0 + PV_R - 1 : oh - 1;
   const int rbase = bound[2 * y0] - ylo;
   int rend = bound[2 * ylast] + bound[2 * ylast + 1] - ylo;
   if (rend - rbase > vspan) rend = rbase + vspan;
-  const int* k = pv_lds + wv * 4 * vspan;
+  const int* k = pv_lds + wv * PV_R * vspan;
   const uint8_t* p = tmp + (tc * nrows + rbase) * (size_t)ow + (size_t)x4 * 4;
-  int acc[4][4];
+  int acc[PV_R][4];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr)
+  for (int rr = 0; rr < PV_R; ++rr)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[rr][c] = 1 << 21;
-#pragma unroll 2
+#pragma unroll 4
   for (int i = 0; i < rend - rbase; ++i) {
     const uint32_t u = *reinterpret_cast<const uint32_t*>(p + (size_t)i * ow);
     const int b0 = (int)(u & 255u), b1 = (int)((u >> 8) & 255u), b2 = (int)((u >> 16) & 255u), b3 = (int)(u >> 24);
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < PV_R; ++rr) {
       const int w = k[rr * vspan + i];
       acc[rr][0] += __mul24(w, b0); acc[rr][1] += __mul24(w, b1); acc[rr][2] += __mul24(w, b2); acc[rr][3] += __mul24(w, b3);
     }
   }
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr)
+  for (int rr = 0; rr < PV_R; ++rr)
     if (y0 + rr < oh)
       *reinterpret_cast<uint32_t*>(out + (tc * oh + y0 + rr) * (size_t)ow + (size_t)x4 * 4) =
           clip8(acc[rr][0]) | (clip8(acc[rr][1]) << 8) | (clip8(acc[rr][2]) << 16) | (clip8(acc[rr][3]) << 24);
@@ -402,9 +403,9 @@ static int preprocess_impl(const uint8_t* frames, int layout, int T, int H, int 
   // a 32-column chunk x 64 rows to fit the 64 KB of LDS a workgroup may use (scale factors up to ~14); the horizontal
   // tables live on the device, so the span bound is computed from the geometry: 32 * scale + taps
   const bool aligned = out_w % 4 == 0 && ((uintptr_t)workspace & 3) == 0 && ((uintptr_t)out & 3) == 0;
-  // input rows that four consecutive output rows can touch: the first row of the fourth starts at most 3 * scale + 1 rows
-  // after the first's and adds its vk taps; vk = 2 * ceil(2 * scale) + 1 bounds the scale: scale <= (vk - 1) / 4
-  const int vspan = vk > 1 ? (3 * (vk - 1) + 3) / 4 + vk + 2 : 4;
+  // input rows that PV_R consecutive output rows can touch: the last row's taps start at most (PV_R - 1) * scale + 1 rows after
+  // the first's and add vk rows; vk = 2 * ceil(2 * scale) + 1 bounds the scale: scale <= (vk - 1) / 4
+  const int vspan = vk > 1 ? ((PV_R - 1) * (vk - 1) + 3) / 4 + vk + 2 : PV_R;
   // matrix-pipe horizontal pass: the caller supplies the digit-split tap matrices (tspo_amd/preprocess.py builds them with
   // the tap tables); needs 16-column blocks, at most 4 K blocks of 64 input columns per block and planes that fit in LDS
   if (mfma_taps && aligned && out_w % 16 == 0 && mfma_nkb >= 1 && mfma_nkb <= 4 && hk > 1) {
@@ -425,8 +426,8 @@ static int preprocess_impl(const uint8_t* frames, int layout, int T, int H, int 
         if (mfma_nkb == 1) PM_LAUNCH(1, 1); else if (mfma_nkb == 2) PM_LAUNCH(1, 2); else if (mfma_nkb == 3) PM_LAUNCH(1, 3); else PM_LAUNCH(1, 4);
       }
 #undef PM_LAUNCH
-      const size_t g4 = (size_t)T * 3 * ((out_h + 15) / 16) * ((out_w / 4 + 63) / 64);
-      hipLaunchKernelGGL(resample_v4_kernel, dim3((unsigned)g4), dim3(256), (size_t)16 * vspan * 4, st, (const uint8_t*)workspace, T,
+      const size_t g4 = (size_t)T * 3 * ((out_h + 4 * PV_R - 1) / (4 * PV_R)) * ((out_w / 4 + 63) / 64);
+      hipLaunchKernelGGL(resample_v4_kernel, dim3((unsigned)g4), dim3(256), (size_t)4 * PV_R * vspan * 4, st, (const uint8_t*)workspace, T,
                          nrows, out_w, vcoef, vbound, out_h, vk, ylo, vspan, out);
       return tspo::check_launch("preprocess_frames");
     }
@@ -448,8 +449,8 @@ static int preprocess_impl(const uint8_t* frames, int layout, int T, int H, int 
     else
       hipLaunchKernelGGL(resample_h_lds_kernel<1>, dim3(grid), dim3(256), lds_bytes, st, frames, in_bytes, T, H, W, hcoef, hbound,
                          out_w, hk, ylo, nrows, nrb, nchunk, pitch, (uint8_t*)workspace);
-    const size_t g4 = (size_t)T * 3 * ((out_h + 15) / 16) * ((out_w / 4 + 63) / 64);
-    hipLaunchKernelGGL(resample_v4_kernel, dim3((unsigned)g4), dim3(256), (size_t)16 * vspan * 4, st, (const uint8_t*)workspace, T,
+    const size_t g4 = (size_t)T * 3 * ((out_h + 4 * PV_R - 1) / (4 * PV_R)) * ((out_w / 4 + 63) / 64);
+    hipLaunchKernelGGL(resample_v4_kernel, dim3((unsigned)g4), dim3(256), (size_t)4 * PV_R * vspan * 4, st, (const uint8_t*)workspace, T,
                        nrows, out_w, vcoef, vbound, out_h, vk, ylo, vspan, out);
     return tspo::check_launch("preprocess_frames");
   }
