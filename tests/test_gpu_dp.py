@@ -143,6 +143,10 @@ def test_gradient_accumulation_equals_concatenated_batch():
     assert "grad_norm_scale" in s2 and calls == [acc.n_train] and acc.step_no == 1
     n = one.n_train
     np.testing.assert_allclose(acc.flat[:n].cpu().numpy(), one.flat[:n].cpu().numpy(), rtol=1e-5, atol=5e-4 * 1e-3)
+    # the per-prompt loss a micro-step reports does not depend on the accumulation setting (it is averaged by the caller)
+    ref_loss = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W, max_grad_norm=MAX_NORM).step(
+        f, t, c, lambda idx: rew, G, K, TAU, noise=noise)["loss"]
+    assert torch.equal(torch.cat([s1["loss"], s2["loss"]]), ref_loss)
     # linear-decay schedule of the reference's HF trainer: lr(step) drives the fused AdamW
     sch = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W, lr_schedule=linear_decay_lr(5e-4, 10))
     st = sch.step(f, t, c, lambda idx: rew, G, K, TAU, noise=noise)
@@ -178,6 +182,22 @@ def test_fused_gradient_norm_equals_the_separate_pass(monkeypatch):
     assert fused._norm_np == 0
     fused.step(f, t, c, lambda idx: rew, G, K, TAU, noise=noise)
     assert seen[-1] is True
+
+
+def test_policy_ops_validate_rollout_indices(monkeypatch):
+    """The policy-gradient kernels find membership by binary search: index lists must be strictly ascending per rollout
+    (checked under ops.DEBUG_CHECKS / TSPO_DEBUG_CHECKS=1), and a group needs at least two rollouts."""
+    f, t, c, noise, rew = (x.to(DEV) for x in _batch(2))
+    tr = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W)
+    _, idx, logp, ctx = tr.rollout(f, t, c, G, K, TAU, noise=noise)
+    with pytest.raises(ValueError, match="G >= 2"):
+        ops.grpo_pg_grad(rew[:, :1], logp, idx[:, :1])
+    monkeypatch.setattr(ops, "DEBUG_CHECKS", True)
+    ops.grpo_pg_grad(rew, logp, idx)                                   # ascending lists pass
+    with pytest.raises(ValueError, match="ascending"):
+        ops.grpo_pg_grad(rew, logp, idx.flip(-1))
+    with pytest.raises(ValueError, match="ascending"):
+        tr.backward(ctx, f, t, logp, idx.flip(-1), rew)
 
 
 def test_rollout_context_is_validated():

@@ -122,6 +122,26 @@ def test_weight_caches_see_in_place_updates():
         m.mlp[2].bias.add_(1.0)                                    # in-place op on the parameter: bumps _version
         s4, _ = m(img, txt, clip, window_size=12)
         assert not torch.equal(s4, s3)
+    # two graphs alive across a parameter update: the earlier graph's backward must use the weights ITS forward used
+    m3 = MultiModal_Align(dim=64, num_heads=8).to(DEV)
+    m3.load_state_dict({k: T_(v) for k, v in synth.selector_state(64, seed=4, std=0.1, bias_std=0.05).items()})
+    ref = MultiModal_Align(dim=64, num_heads=8).to(DEV)
+    ref.load_state_dict(m3.state_dict())
+    sa, _ = m3(img, txt, clip, window_size=12)                      # graph A (non-flat parameters: packed copy)
+    m3.mlp[0].weight.data.mul_(2.0)                                 # "optimizer step" through p.data
+    sb, _ = m3(img, txt, clip, window_size=12)                      # graph B repacks the shared buffer in place
+    sa.sum().backward()
+    sr, _ = ref(img, txt, clip, window_size=12)
+    sr.sum().backward()
+    assert torch.equal(m3.mlp[2].weight.grad, ref.mlp[2].weight.grad)    # A's gradients: the pre-update weights
+    assert not torch.equal(sb.detach(), sa.detach())
+    mf = MultiModal_Align(dim=64, num_heads=8).to(DEV)
+    mf.load_state_dict(ref.state_dict())
+    mf.flatten_parameters()
+    sf, _ = mf(img, txt, clip, window_size=12)
+    mf._flat.mul_(1.5)                                              # in-place update of the live bucket before the backward
+    with pytest.raises(RuntimeError, match="modified in place"):
+        sf.sum().backward()
     # flat mode: gradient views survive zero_grad(set_to_none=True) and an optimizer's zero_grad()
     m2 = MultiModal_Align(dim=64, num_heads=8).to(DEV)
     m2.load_state_dict({k: T_(v) for k, v in synth.selector_state(64, seed=4, std=0.1, bias_std=0.05).items()})
