@@ -777,6 +777,99 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
   }
 }
 
+#ifdef TSPO_DEV_HOOKS
+// Round-3 A/B (dev builds, TSPO_ATTN_W8=1; measured 17.3 ms per forward against 13.0 ms for the shipped kernel on the same
+// box - twice the fragment reads per MFMA and 24 spilled registers cost more than the extra waves hide): the same item with EIGHT waves of TWO query tiles each (32 queries per wave) and at most 128 registers, so
+// that two workgroups = four waves share a SIMD instead of two: the softmax is a chain of dependent vector instructions
+// (quarter-rate exp2 on MFMA results) and two waves per SIMD leave its latencies exposed (MFMA busy 31 %, 42 % of wave
+// cycles waiting for issue).  Costs twice the K / V^T fragment reads per MFMA (each read feeds 2 instead of 4).
+__global__ __launch_bounds__(512, 4) void clip_attn257w8_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int C,
+                                                                float scale) {
+  constexpr int S = 257;
+  __shared__ __attribute__((aligned(16))) char lds[A4_LDS_BYTES];
+  char* Ks = lds;
+  char* Vt = lds + AT_KEYS * 128;
+  float* part = reinterpret_cast<float*>(lds + A4_PART_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+  const int item = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
+  const int h = item % (int)gridDim.x;
+  const size_t f = item / (int)gridDim.x;
+  const size_t ld = (size_t)3 * C;
+  const bf16_t* base = qkv + f * S * ld + (size_t)h * 64;
+  bf16x8 qf2[2][2];
+  {
+    uint4 kv[5], vv[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int id = tid + i * 512;
+      const int row = id >> 3, c = id & 7;
+      const int rc = row < S ? row : S - 1;
+      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + C + c * 8);
+      vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + 2 * C + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int id = tid + i * 512;
+      const int row = id >> 3, c = id & 7;
+      if (row < AT_KEYS) {
+        const uint4 z = {0u, 0u, 0u, 0u};
+        const uint4 k4 = row < S ? kv[i] : z, v4 = row < S ? vv[i] : z;
+        *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = k4;
+        *reinterpret_cast<uint4*>(Vt + ((row >> 5) * 4 + (c >> 1)) * A4_VSUB + (row & 31) * 32 + (c & 1) * 16) = v4;
+      }
+      if (i == 0) attn257_load_q<2>(base, ld, wid * 2, l15, q4, qf2);
+    }
+  }
+  __syncthreads();
+  {
+    float m2[2], l2[2];
+    f32x4 o2[2][4];
+    attn257_blocks<2>(qf2, Ks, Vt, scale, 0, 3, l15, q4, m2, l2, o2);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int qrow = (wid * 2 + n) * 16 + l15;
+      const float inv = 1.f / l2[n];
+      bf16_t* orow = out + (f * S + qrow) * (size_t)C + (size_t)h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o2[n][dt][0] * inv, o2[n][dt][1] * inv);
+        pk.y = pack_bf16x2(o2[n][dt][2] * inv, o2[n][dt][3] * inv);
+        *reinterpret_cast<uint2*>(orow + dt * 16 + q4 * 4) = pk;
+      }
+    }
+  }
+  if (wid < 3) {
+    float m1[1], l1[1];
+    f32x4 o1[1][4];
+    bf16x8 qf1[1][2];
+    attn257_load_q<1>(base, ld, 16, l15, q4, qf1);
+    attn257_blocks<1>(qf1, Ks, Vt, scale, wid, wid + 1, l15, q4, m1, l1, o1);
+    if (l15 == 0) {
+      float* pw = part + wid * 68;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[dt * 16 + q4 * 4 + r] = o1[0][dt][r];
+      if (q4 == 0) { pw[64] = m1[0]; pw[65] = l1[0]; }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float ma = part[64], mb = part[68 + 64], mc = part[136 + 64];
+    const float m = fmaxf(ma, fmaxf(mb, mc));
+    const float wa = __builtin_amdgcn_exp2f(ma - m), wb = __builtin_amdgcn_exp2f(mb - m), wc = __builtin_amdgcn_exp2f(mc - m);
+    const float l = part[65] * wa + part[68 + 65] * wb + part[136 + 65] * wc;
+    const float ov = (part[tid] * wa + part[68 + tid] * wb + part[136 + tid] * wc) / l;
+    const float on = __shfl_down(ov, 1, 64);
+    if ((tid & 1) == 0)
+      *reinterpret_cast<uint32_t*>(out + (f * S + 256) * (size_t)C + (size_t)h * 64 + tid) = pack_bf16x2(ov, on);
+  }
+}
+#endif  // TSPO_DEV_HOOKS (clip_attn257w8_kernel)
+
 // ===========================================================================
 // (dev builds only - measured, not shipped: see the end of this comment)
 // Persistent form of the kernel above: one 8-wave workgroup per CU walks over (frame, head) items.  K and V of item i+1
@@ -1420,6 +1513,8 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       hipLaunchKernelGGL(clip_attn257p_kernel<1>, dim3(256), dim3(512), 0, st, b.qkv, b.a, C, c.heads, c.heads * n_frames, 0.125f);
     else if (S == 257 && attnp_abl == 2)
       hipLaunchKernelGGL(clip_attn257p_kernel<2>, dim3(256), dim3(512), 0, st, b.qkv, b.a, C, c.heads, c.heads * n_frames, 0.125f);
+    else if (S == 257 && getenv("TSPO_ATTN_W8") && getenv("TSPO_ATTN_W8")[0])
+      hipLaunchKernelGGL(clip_attn257w8_kernel, dim3(c.heads, n_frames), dim3(512), 0, st, b.qkv, b.a, C, 0.125f);
     else if (S == 257 && (long)c.heads * n_frames >= 512 && getenv("TSPO_ATTN_PERSISTENT"))
       hipLaunchKernelGGL(clip_attn257p_kernel<0>, dim3(256), dim3(512), 0, st, b.qkv, b.a, C, c.heads, c.heads * n_frames, 0.125f);
     else
