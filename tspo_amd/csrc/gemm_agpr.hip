@@ -317,7 +317,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
   int dcount = 16, pm0 = 0, pn0 = 0;
   auto defer_store = [&](auto j_) {
     constexpr int j = decltype(j_)::value;
-    if ((DEV & 32) && dcount < 16) {
+    if ((DEV & 64) && dcount < 16) {      // thin form: ONE store per K-step (behind column tile 4), 16 K-steps to drain
+      if (j == 4) {
+        const int sidx = dcount, mi = sidx >> 1, pr = sidx & 1;
+        const int m = pm0 + wm * 128 + mi * 16 + l15;
+        const int n = pn0 + (wn * 2 + 1) * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
+        if (m < g.M && n < g.N) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + (size_t)m * g.N + n) = sw_[0];
+      }
+    } else if ((DEV & 32) && dcount < 16) {
       const int sidx = dcount + j, mi = sidx >> 1, pr = sidx & 1;
       const int m = pm0 + wm * 128 + mi * 16 + l15;
       const int n = pn0 + (wn * 2 + 1) * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
@@ -339,7 +346,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     khalf(std::false_type{}, std::integral_constant<int, 1>{}, fa1, fa0, nxt, 0, [&](auto j_, auto ph_) {
       if (decltype(ph_)::value == 0) swrite_a(j_, sa, cb); else { gload_a(j_, sa); defer_store(j_); }
     });
-    if ((DEV & 32) && dcount < 16) dcount += 8;
+    if ((DEV & 64) && dcount < 16) dcount += 1;
+    else if ((DEV & 32) && dcount < 16) dcount += 8;
     adv_a();
     if (!RW) __builtin_amdgcn_s_waitcnt(0xC07F);
     ++it;
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
     else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
     probe(t, 2);
-    if (DEV & 32) { dcount = 0; pm0 = m0; pn0 = n0; }
+    if (DEV & (32 | 64)) { dcount = 0; pm0 = m0; pn0 = n0; }
     c_s += nwl;
     // the next tile's first fragments again, AFTER the epilogue: the copies read in the last [B] are dead here, so
     // nothing but the staging registers stays live across the epilogue (stale data after the last tile, never used)
@@ -433,6 +441,7 @@ int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
     return launch_gemm_a7<EPI, false, true, false, 5>(h, st);
   }
   if (g.variant == 81) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true>(h, st); }   // slice 1 of every tile not stored
+  if (g.variant == 79) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true, false, 64>(h, st); }   // ... one store per K-step
   if (g.variant == 80) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true, false, 32>(h, st); }   // ... and stored (dummy data) from the next tile's first two K-steps
   if (g.variant >= 91 && g.variant <= 94) {   // epilogue entry de-phased by 128 / 256 / 512 / 1024 cycles per wave
     GemmArgs h = g;
