@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     });
   };
 
+  unsigned long long bar_cycles = 0, ks_cycles = 0, ks_last = 0, ks_count = 0;
   int it = 0, c_s = wl;
   // DEV bit 5 (timing experiment, wrong results): "deferred stores" - the epilogue leaves slice 1 of the tile unstored and the
   // next tile's first two K-steps issue those 16 stores per wave (dummy data: the W staging registers) behind their MFMAs
@@ -340,6 +341,19 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
       if (decltype(ph_)::value == 0) swrite_w(j_, nb); else gload_w(j_);
     });
     adv_w();
+#ifdef TSPO_DEV_HOOKS
+    if (DEV & 128) {   // probe: cycles this wave spends in the per-K-step wait + barrier, and in a whole K-step
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bar_cycles += tb1 - tb0;
+      if (ks_last) ks_cycles += tb0 - ks_last;
+      ks_last = tb0;
+      ++ks_count;
+    } else
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage it+1 complete in LDS; buffer cb fully read
     __builtin_amdgcn_s_waitcnt(0xC07F);   // (the same wait as a builtin: free at run time, keeps hipcc's wait model exact)
     // [B]: K-half 1; fragments of K-half 0 of stage it+1; A pieces of set `sa`: S_j(it+2) -> buffer cb, then G_j(it+4)
@@ -398,6 +412,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     __builtin_amdgcn_s_waitcnt(0xC07F);
     probe(t, 3);
   }
+#ifdef TSPO_DEV_HOOKS
+  if ((DEV & 128) && lane == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos)) + ((size_t)blockIdx.x * 4 + wid) * 3;
+    o[0] = bar_cycles; o[1] = ks_cycles; o[2] = ks_count;
+  }
+#endif
 }
 
 template <int EPI, bool A2, bool PRE0, bool RW = false, int DEV = 0>
@@ -441,6 +461,12 @@ int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
     return launch_gemm_a7<EPI, false, true, false, 5>(h, st);
   }
   if (g.variant == 81) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true>(h, st); }   // slice 1 of every tile not stored
+  if (g.variant == 78) {                                                  // K-step wait/barrier probe: needs tspo_dev_set_debug()
+    GemmArgs h = g;
+    h.pos = reinterpret_cast<const float*>(tspo_dev_debug_ptr());
+    if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_agpr: variant 78 without a debug buffer");
+    return launch_gemm_a7<EPI, false, true, false, 128>(h, st);
+  }
   if (g.variant == 79) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true, false, 64>(h, st); }   // ... one store per K-step
   if (g.variant == 80) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true, false, 32>(h, st); }   // ... and stored (dummy data) from the next tile's first two K-steps
   if (g.variant >= 91 && g.variant <= 94) {   // epilogue entry de-phased by 128 / 256 / 512 / 1024 cycles per wave
