@@ -77,6 +77,25 @@ __global__ __launch_bounds__(256, 1) void load_kernel(const uint16_t* A, int ite
   if (acc.x == 0x12345678u) sink[0] = acc.y;
 }
 
+// cost of publishing a workgroup's results to the rest of the chip inside one launch (agent-scope release + atomic):
+// every workgroup writes 64 KB of its own, then FENCE: __threadfence() + atomicAdd on a per-group counter
+template <bool FENCE>
+__global__ __launch_bounds__(256, 1) void publish_kernel(uint16_t* C, unsigned* counters, int iters) {
+  const int tid = threadIdx.x;
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4* dst = reinterpret_cast<u4*>(C + (size_t)blockIdx.x * 32768);
+  const u4 v = {(unsigned)tid, 1u, 2u, 3u};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[j * 256 + tid] = v;
+    if (FENCE) {
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) atomicAdd(counters + (blockIdx.x >> 3), 1u);
+    }
+  }
+}
+
 int main() {
   const int M = 257 * 1024, N = 3072, tilesN = N / 256, ntiles = (M / 256) * tilesN;
   uint16_t* C;
@@ -156,6 +175,20 @@ int main() {
     runld("1 KB contiguous, streamed", load_kernel<0>, 6u << 20, 96);
     runld("8 rows x 128 B pitch 2 KB, streamed (16 K-steps)", load_kernel<2048>, 512 * 2048 * 4, 16);
     runld("8 rows x 128 B pitch 8 KB, streamed (64 K-steps)", load_kernel<8192>, 512 * 8192, 64);
+  }
+  {
+    unsigned* ctr; hipMalloc(&ctr, 4096); hipMemset(ctr, 0, 4096);
+    auto runpub = [&](const char* name, auto kern) {
+      const int iters = 200;
+      for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, C, ctr, iters);
+      hipEventRecord(e0);
+      for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, C, ctr, iters);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+      printf("PUBLISH %-34s: %7.3f ms for %d x 64 KB per workgroup = %6.2f us per publication\n", name, ms, iters, ms * 1e3 / iters);
+    };
+    runpub("64 KB stores only", publish_kernel<false>);
+    runpub("64 KB stores + fence + atomic", publish_kernel<true>);
   }
   // fewer workgroups: is ~16 B/clk a per-CU limit or the XCD's L2 write bandwidth shared by its 32 CUs?
   for (int grid : {8, 32, 64, 128, 256}) {
