@@ -420,6 +420,189 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
 #endif
 }
 
+
+// ===========================================================================
+// "a9": the same tile, wave layout, AGPR accumulators and epilogue as a7, but the operands reach LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds) in the schedule of the vendor library's hand-written 256x256x64 kernel for this chip
+// (hipBLASLt `Custom_Cijk_Alik_Bljk_BBS_..._MT256x256x64_MI16x16x1`, read from its disassembly as a specification;
+// DESIGN 4.4): the WHOLE K-step's fragments live in registers (4 x 32 VGPRs), so a ring buffer can be refilled two stages
+// ahead as soon as its second K-half has been read into registers - no staging VGPRs, no ds_write, 16 instead of 32 staging
+// instructions per wave and K-step:
+//   K-step it (buffer cb = it & 1 holds stage it, nb stage it+1 in flight, fa0/fw0 = K-half 0 of stage it):
+//     K-half 0 MFMAs | A fragments of K-half 1 <- cb | B1 | DMA A(it+2) -> cb.A, W fragments of K-half 1 <- cb | B2 |
+//                    DMA A(it+2) rest, DMA W(it+2) -> cb.W
+//     K-half 1 MFMAs | DMA W(it+2) | vmcnt(13): stage it+1 landed, B3 | fragments of K-half 0 of stage it+1 <- nb
+// The XOR swizzle of the LDS image (chunk c of row r at c ^ (r & 7)) is applied on the global SOURCE address (an LDS-DMA
+// destination is lane-linear).  DMA instructions are inline asm: hipcc's wait-count pass does not see them, so its own
+// vmcnt waits (epilogue loads / stores) can only over-wait, and the three waits that order DMA against the fragment reads
+// are written here explicitly.
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int tilesM, int ngrp) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE];  // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int nk = g.K / GT_BK;   // >= 2
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
+  const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
+  const int panels = (tilesM - pset + npset - 1) / npset;
+  const int ntile_x = panels * n_per;
+  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
+  if (my_tiles == 0) return;
+  A4_FENCE();   // claims a[0:255] for this kernel
+
+  // ---- LDS-DMA: piece P = wid*8 + q of a region = rows 8P..8P+7 (1 KB); lane (rin, slot) brings global chunk slot ^ rin ----
+  const int rin = lane >> 3, slot = lane & 7;
+  const unsigned lane_goff = ((unsigned)rin * (unsigned)g.K + (unsigned)((slot ^ rin) << 3)) * 2u;
+  const unsigned piece_stride = 8u * (unsigned)g.K * 2u;
+  const unsigned lds0 = (unsigned)(size_t)lds + (unsigned)wid * 8192u;
+  const unsigned soff0 = (unsigned)wid * 8u * piece_stride;
+  int d_kt = 0, d_s = wl;   // the stage the NEXT K-step's DMA brings: K-step inside the tile, tile
+  auto rsrc_a = [&](int s_) {
+    const int m0 = ((s_ / n_per) * npset + pset) * G3_BM;
+    const long r = m0 < g.M ? ((long)(g.M - m0) * g.K * 2) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)(m0 < g.M ? m0 : 0) * g.K), 0,
+                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
+  };
+  auto rsrc_w = [&](int s_) {
+    const int n0 = (grp * n_per + s_ % n_per) * G3_BN;
+    const long r = n0 < g.N ? ((long)(g.N - n0) * g.K * 2) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)(n0 < g.N ? n0 : 0) * g.K), 0,
+                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t a_rs = rsrc_a(d_s), w_rs = rsrc_w(d_s);
+  auto adv_d = [&]() {
+    if (++d_kt == nk) {
+      asm volatile("" ::: "memory");   // keeps the tile switch (two divisions, two descriptors) a BRANCH: if-converted it runs every K-step
+      d_kt = 0; d_s += nwl; a_rs = rsrc_a(d_s); w_rs = rsrc_w(d_s);
+    }
+  };
+  auto dma_a = [&](auto q_, int buf) {
+    constexpr int q = decltype(q_)::value;
+    const unsigned dst = lds0 + (unsigned)buf * G3_STAGE + q * 1024u;
+    const unsigned so = soff0 + q * piece_stride + (unsigned)d_kt * (GT_BK * 2u);
+    const unsigned vo = lane_goff;             // (named copies: clang does not capture a variable that only an asm operand uses)
+    const __amdgpu_buffer_rsrc_t rs = a_rs;
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(so) : "memory");
+  };
+  auto dma_w = [&](auto q_, int buf) {
+    constexpr int q = decltype(q_)::value;
+    const unsigned dst = lds0 + (unsigned)buf * G3_STAGE + G3_BM * 128u + q * 1024u;
+    const unsigned so = soff0 + q * piece_stride + (unsigned)d_kt * (GT_BK * 2u);
+    const unsigned vo = lane_goff;
+    const __amdgpu_buffer_rsrc_t rs = w_rs;
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(so) : "memory");
+  };
+
+  // ---- fragments: both K-halves of a stage, A and W: 4 x 8 x 4 VGPRs ----
+  const int sw = l15 & 7;
+  const int fbaseA = (wm * 128 + l15) * 128, fbaseW = G3_BM * 128 + (wn * 128 + l15) * 128;
+  const int co0 = (q4 ^ sw) << 4, co1 = ((4 + q4) ^ sw) << 4;
+  i32x4 fa0[8], fa1[8], fw0[8], fw1[8];
+  auto ldfrag = [&](const char* p) { return *reinterpret_cast<const i32x4*>(p); };
+
+  // ---- prologue: stages 0 and 1 in flight, stage 0 landed, its K-half 0 in registers ----
+  sfor<0, 8>([&](auto q_) { dma_a(q_, 0); dma_w(q_, 0); });
+  adv_d();
+  sfor<0, 8>([&](auto q_) { dma_a(q_, 1); dma_w(q_, 1); });
+  adv_d();
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(lds + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(lds + fbaseW + i * 2048 + co0); }
+
+  int it = 0, c_s = wl;
+  auto kstep = [&](auto zero_, auto last_) {
+    constexpr bool ZERO = decltype(zero_)::value, LAST = decltype(last_)::value;
+    const int cb = it & 1;
+    const char* cur = lds + cb * G3_STAGE;
+    const char* nxt = lds + (cb ^ 1) * G3_STAGE;
+    // ---- K-half 0 ----
+    sfor<0, 8>([&](auto nn_) {
+      constexpr int nn = decltype(nn_)::value;
+      sfor<0, 8>([&](auto mi_) {
+        constexpr int mi = decltype(mi_)::value;
+        constexpr int idx = nn * 8 + mi;
+        { const i32x4 wf = fw0[nn], af = fa0[mi]; if (ZERO) A4_MFMA_Z(nn, mi, wf, af); else A4_MFMA(nn, mi, wf, af); }
+        if constexpr (idx < 16 && idx % 2 == 0) fa1[idx / 2] = ldfrag(cur + fbaseA + (idx / 2) * 2048 + co1);
+        if constexpr (idx == 21) {   // B1: every wave holds its A fragments of this stage -> region cb.A may be refilled
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        if constexpr (idx >= 22 && idx <= 30 && idx % 2 == 0) dma_a(std::integral_constant<int, (idx - 22) / 2>{}, cb);
+        if constexpr (idx >= 23 && idx <= 31 && idx % 2 == 1) fw1[(idx - 23) / 2] = ldfrag(cur + fbaseW + ((idx - 23) / 2) * 2048 + co1);
+        if constexpr (idx == 33 || idx == 35 || idx == 37) fw1[5 + (idx - 33) / 2] = ldfrag(cur + fbaseW + (5 + (idx - 33) / 2) * 2048 + co1);
+        if constexpr (idx == 47) {   // B2: ... and its W fragments -> cb.W may be refilled
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        if constexpr (idx == 48 || idx == 51 || idx == 54) dma_a(std::integral_constant<int, 5 + (idx - 48) / 3>{}, cb);
+        if constexpr (idx == 57 || idx == 60) dma_w(std::integral_constant<int, (idx - 57) / 3>{}, cb);
+      });
+      A4_FENCE();
+    });
+    // ---- K-half 1 ----
+    sfor<0, 8>([&](auto nn_) {
+      constexpr int nn = decltype(nn_)::value;
+      sfor<0, 8>([&](auto mi_) {
+        constexpr int mi = decltype(mi_)::value;
+        constexpr int idx = nn * 8 + mi;
+        { const i32x4 wf = fw1[nn], af = fa1[mi]; A4_MFMA(nn, mi, wf, af); }
+        if constexpr (idx == 2 || idx == 6 || idx == 10) dma_w(std::integral_constant<int, 2 + (idx - 2) / 4>{}, cb);
+        if constexpr (idx == 20) {   // B3: this wave's pieces of stage it+1 have landed (13 younger DMAs may fly) -> everybody's
+          asm volatile("s_waitcnt vmcnt(13)\n\ts_barrier" ::: "memory");
+        }
+        if constexpr (idx == 24) dma_w(std::integral_constant<int, 5>{}, cb);
+        if constexpr (idx == 28) dma_w(std::integral_constant<int, 6>{}, cb);
+        if constexpr (idx == 55) dma_w(std::integral_constant<int, 7>{}, cb);
+        if constexpr (!LAST) {   // K-half 0 of stage it+1 (after a tile's last K-step: behind the epilogue instead)
+          if constexpr (idx == 21 || idx == 22 || idx == 23) fa0[idx - 21] = ldfrag(nxt + fbaseA + (idx - 21) * 2048 + co0);
+          if constexpr (idx == 25 || idx == 26) fa0[idx - 22] = ldfrag(nxt + fbaseA + (idx - 22) * 2048 + co0);
+          if constexpr (idx == 29) fa0[5] = ldfrag(nxt + fbaseA + 5 * 2048 + co0);
+          if constexpr (idx == 31 || idx == 32) fa0[idx - 25] = ldfrag(nxt + fbaseA + (idx - 25) * 2048 + co0);
+          if constexpr (idx == 33 || idx == 34) fw0[idx - 33] = ldfrag(nxt + fbaseW + (idx - 33) * 2048 + co0);
+          if constexpr (idx == 37) fw0[2] = ldfrag(nxt + fbaseW + 2 * 2048 + co0);
+          if constexpr (idx == 40) fw0[3] = ldfrag(nxt + fbaseW + 3 * 2048 + co0);
+          if constexpr (idx == 42) fw0[4] = ldfrag(nxt + fbaseW + 4 * 2048 + co0);
+          if constexpr (idx == 45) fw0[5] = ldfrag(nxt + fbaseW + 5 * 2048 + co0);
+          if constexpr (idx == 48) fw0[6] = ldfrag(nxt + fbaseW + 6 * 2048 + co0);
+          if constexpr (idx == 51) fw0[7] = ldfrag(nxt + fbaseW + 7 * 2048 + co0);
+        }
+      });
+      A4_FENCE();
+    });
+    adv_d();
+    ++it;
+  };
+
+  for (int t = 0; t < my_tiles; ++t) {
+    const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
+    kstep(std::true_type{}, std::false_type{});
+    for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
+    EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
+    epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
+    kstep(std::false_type{}, std::true_type{});
+    if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
+    else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
+    c_s += nwl;
+    const char* nbuf = lds + (it & 1) * G3_STAGE;              // the next tile's first fragments, behind the epilogue
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(nbuf + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(nbuf + fbaseW + i * 2048 + co0); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two stages requested past the last tile (zero-length resources)
+}
+
+template <int EPI>
+int launch_gemm_a9(GemmArgs g, hipStream_t st) {
+  const int tilesM = (g.M + G3_BM - 1) / G3_BM;
+  g.tilesN = (g.N + G3_BN - 1) / G3_BN;
+  g.nwg = tilesM * g.tilesN;
+  int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
+  if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
+  hipLaunchKernelGGL((gemm_bf16_a9_kernel<EPI>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
+  return tspo::check_launch("gemm_bf16_a9");
+}
+
 template <int EPI, bool A2, bool PRE0, bool RW = false, int DEV = 0>
 int launch_gemm_a7(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
@@ -441,6 +624,10 @@ static void* tspo_dev_debug_ptr() { return g_dev_debug; }
 namespace {
 template <int EPI>
 int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
+  if (g.variant == 77) {
+    if (g.K < 2 * GT_BK) return tspo::set_err(TSPO_EINVAL, "gemm_agpr: K=%d too small for the DMA kernel", g.K);
+    return launch_gemm_a9<EPI>(g, st);
+  }
   if ((g.K / GT_BK) % 2 != 0 || g.K < 2 * GT_BK)
     return tspo::set_err(TSPO_EINVAL, "gemm_agpr: K=%d must be a multiple of 128", g.K);
 #ifdef TSPO_DEV_HOOKS

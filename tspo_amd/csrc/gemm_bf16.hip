@@ -923,7 +923,7 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   g.variant = v;
   if (v == 1) return launch_gemm_v1<EPI>(g, st);
   if (v == 6) return launch_gemm_p256<EPI, 1, 6>(g, st);     // 8-wave LDS-DMA ring: interleaved DMA issue + L2 prefetch of A 6 K-steps ahead
-  if (v >= 78 && v < 100) return tspo::gemm_bf16_agpr(EPI, g, st);   // 4-wave kernel with AGPR accumulators (gemm_agpr.hip)
+  if (v >= 77 && v < 100) return tspo::gemm_bf16_agpr(EPI, g, st);   // 4-wave kernel with AGPR accumulators (gemm_agpr.hip)
 #ifdef TSPO_DEV_HOOKS
   // A/B variants and ablations (tools/bench_gemm.py, tools/probe_gemm_wait.py); several compute wrong results on purpose
   if (v == 65) return launch_gemm_p256<EPI, 1, 0>(g, st);    // no L2 prefetch
@@ -968,7 +968,7 @@ int launch_gemm_ln(GemmArgs g, hipStream_t st) {
   if (EPI == GE_RESID_ST ? !g.spart : !(g.lnc && g.rstats))
     return tspo::set_err(TSPO_EINVAL, "gemm: epilogue %d without its statistics pointers", EPI);
   { const int v = g.variant ? g.variant : default_big_variant(g.K);
-    if (v >= 78 && v < 100) { GemmArgs h = g; h.variant = v; return tspo::gemm_bf16_agpr(EPI, h, st); } }
+    if (v >= 77 && v < 100) { GemmArgs h = g; h.variant = v; return tspo::gemm_bf16_agpr(EPI, h, st); } }
   return launch_gemm_p256<EPI, 1, 6>(g, st);
 }
 }  // namespace
