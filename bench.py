@@ -439,7 +439,7 @@ def main():
                 pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
-                "alg_bytes_per_launch_avg": alg_bytes_per_launch(c, B * T), "kernel": "gemm_bf16_a7_kernel",
+                "alg_bytes_per_launch_avg": alg_bytes_per_launch(c, B * T), "kernel": "gemm_bf16_a9_kernel",
                 "launches_per_step": pr["gemm_launches"],
                 "avg_launch_ms": round(pr["gemm_ms"] / pr["gemm_launches"], 4),
                 "alg_flop_per_launch_avg": gflop / pr["gemm_launches"],

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -67,30 +69,32 @@ def test_shipped_library_has_no_dev_hooks():
     l = _lib.lib()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    for variant in (2, 8, 9, 60, 69, 70, 71):        # 256x128 ring, compute-only / loads-only ablations, probe, role-split, 16-wave
+    for variant in (2, 8, 9, 60, 69, 70, 71, 72, 76):   # 256x128 ring, compute-only / loads-only ablations, probe, role-split, 16-wave, DMA-kernel lab schedules
         assert l.tspo_gemm_bf16(p, p, p, None, p, _lib.TSPO_BF16, 4096, 4096, 1024, variant << 8, None) == -1
         assert b"not part of this build" in l.tspo_last_error()
     blob = open(_lib.LIB_PATH, "rb").read()
     for name in (b"gemm_bf16_p3_kernel", b"gemm_bf16_s256_kernel", b"gemm_bf16_w16_kernel", b"clip_attn257p_kernel",
-                 b"TSPO_GEMM_VARIANT", b"TSPO_ATTN_ABL", b"TSPO_SEL_SPLIT", b"getenv"):   # no env-driven behaviour either
+                 b"TSPO_GEMM_VARIANT", b"TSPO_ATTN_ABL", b"TSPO_SEL_SPLIT", b"getenv", b"tspo_dma_set_debug"):   # no env-driven behaviour either
         assert name not in blob, name
-    assert b"gemm_bf16_a7_kernel" in blob and b"gemm_bf16_p256_kernel" in blob
+    assert b"gemm_bf16_a9_kernel" in blob and b"gemm_bf16_a7_kernel" in blob and b"gemm_bf16_p256_kernel" in blob
 
 
-def test_agpr_gemm_code_audit(tmp_path):
-    """gemm_agpr.hip keeps 256 accumulators per lane in AGPRs under literal names that the compiler does not know about.
-    That is only sound if hipcc itself never touches an AGPR in that kernel and does not spill inside the MFMA loop:
-    audit the generated gfx950 code of every instantiation (device-only -S compile, ~1 min)."""
+@pytest.mark.parametrize("src,kernel", [("gemm_dma.hip", "gemm_bf16_a9_kernel"), ("gemm_agpr.hip", "gemm_bf16_a7_kernel")])
+def test_agpr_gemm_code_audit(tmp_path, src, kernel):
+    """gemm_dma.hip (production) and gemm_agpr.hip keep 256 accumulators per lane in AGPRs under literal names that the compiler
+    does not know about.  That is only sound if hipcc itself never touches an AGPR in those kernels and does not spill inside
+    the MFMA loop: audit the generated gfx950 code of every instantiation (device-only -S compile, ~1-2 min each).  For the
+    LDS-DMA kernel also: the only m0 writes are the ones in front of its own DMA instructions."""
     import subprocess
     from tspo_amd import build as b
-    asm = tmp_path / "gemm_agpr.s"
+    asm = tmp_path / (src + ".s")
     subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
-                           os.path.join(b.CSRC, "gemm_agpr.hip"), "-o", str(asm)])
+                           os.path.join(b.CSRC, src), "-o", str(asm)])
     txt = open(asm).read()
-    kernels = re.findall(r"^(_ZN\S*gemm_bf16_a7_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end", txt, flags=re.S | re.M)
-    assert len(kernels) == 8, [k[0] for k in kernels]
+    kernels = re.findall(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)\n\.Lfunc_end" % kernel, txt, flags=re.S | re.M)
+    assert len(kernels) == (10 if kernel == "gemm_bf16_a9_kernel" else 8), [k[0] for k in kernels]   # a9: residual forms twice (R in the epilogue / on the matrix pipe)
     for name, body in kernels:
-        inasm, bad = False, []
+        inasm, bad, m0bad = False, [], []
         blocks, cur = [], []
         for ln in body.split("\n"):
             t = ln.strip()
@@ -103,10 +107,15 @@ def test_agpr_gemm_code_audit(tmp_path):
                 inasm = False
             elif not inasm and t and not t.startswith((";", ".")) and (re.search(r"\ba\[?\d+", t) or "accvgpr" in t):
                 bad.append(t)
+            elif not inasm and t and not t.startswith((";", ".")) and re.search(r"\bm0\b", t):
+                m0bad.append(t)
             cur.append(t)
         blocks.append(cur)
         assert not bad, f"{name}: compiler-emitted AGPR access outside the asm statements: {bad[:3]}"
+        if kernel == "gemm_bf16_a9_kernel":
+            assert not m0bad, f"{name}: compiler-emitted m0 use next to the hand-written LDS-DMA: {m0bad[:3]}"
+            assert not any(x.startswith("scratch_") for blk in blocks for x in blk), f"{name}: scratch access"
         for blk in blocks:
             if sum(x.startswith("v_mfma") for x in blk) >= 32:       # the K-loop bodies
                 assert not any(x.startswith("scratch_") for x in blk), f"{name}: scratch access inside an MFMA block"
-        assert body.count("v_mfma_f32_16x16x32_bf16") >= 6 * 64
+        assert body.count("v_mfma_f32_16x16x32_bf16") >= (3 if kernel == "gemm_bf16_a9_kernel" else 6) * 64

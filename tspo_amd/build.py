@@ -10,8 +10,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtspo_hip.so")
-SOURCES = ["sampler.hip", "selector.hip", "gemm_bf16.hip", "gemm_agpr.hip", "clip_vit.hip", "preprocess.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_bf16.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(os.path.dirname(PKG), "include", "tspo_hip.h")]
+SOURCES = ["sampler.hip", "selector.hip", "gemm_bf16.hip", "gemm_agpr.hip", "gemm_dma.hip", "clip_vit.hip", "preprocess.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_bf16.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_agpr_common.h"), os.path.join(os.path.dirname(PKG), "include", "tspo_hip.h")]
 
 
 def _hipcc() -> str:
@@ -29,21 +29,30 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, dev: bool = False, lab: bool = False, only=None) -> str:
     """dev=True adds -DTSPO_DEV_HOOKS: the GEMM A/B variants, ablation branches and timing probes the tools/ scripts use
-    (some compute wrong results on purpose).  The shipped library is built WITHOUT it."""
+    (some compute wrong results on purpose).  lab=True adds -DTSPO_A9_LAB: the schedule A/B variants of the LDS-DMA GEMM.
+    The shipped library is built WITHOUT either.  The translation units compile in parallel (one hipcc per source);
+    only=[...] recompiles just those sources and relinks with the other objects as they are."""
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
-    objs = []
-    for s in SOURCES:
+    flags = (["-DTSPO_DEV_HOOKS"] if dev else []) + (["-DTSPO_A9_LAB"] if lab else [])
+
+    def compile_one(s):
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
-              (["-DTSPO_DEV_HOOKS"] if dev else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        if only is not None and s not in only and os.path.exists(o):
+            return o
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + flags + \
+              ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(o)
+        return o
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -52,5 +61,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv or "--dev" in sys.argv, dev="--dev" in sys.argv)
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    build(force=True if (only or "--force" in sys.argv or "--dev" in sys.argv or "--lab" in sys.argv) else False,
+          dev="--dev" in sys.argv, lab="--lab" in sys.argv, only=only[0] if only else None)
     print(LIB)

@@ -21,152 +21,9 @@
 // synchronisation is one barrier per K-step between four waves running the same in-order stream on separate SIMDs.
 // LDS image as in gemm_bf16.hip: 128-byte rows, 16-byte chunk c of row r at chunk c ^ (r & 7) (here applied by the
 // ds_write address: the 8 lanes of a row cover all 32 banks) -> conflict-free ds_read_b128 fragment reads.
-#include "gemm_epilogue.h"
-#include <type_traits>
-
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-// Development hooks (python -m tspo_amd.build --dev only): epilogue ablations selected at run time through GemmArgs.P and
-// an s_memtime probe of the tile phases (DEV bit 0 of the kernel template).  The shipped library compiles none of it.
-#ifdef TSPO_DEV_HOOKS
-#define A7_ABL(g, n) ((g).P == -(n))
-#else
-#define A7_ABL(g, n) false
-#endif
+#include "gemm_agpr_common.h"
 
 namespace {
-template <int I, int N, class F>
-__device__ __forceinline__ void sfor(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    sfor<I + 1, N>(static_cast<F&&>(f));
-  }
-}
-
-#define A4_ALL_AGPRS                                                                                                     \
-  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18",  \
-      "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35",   \
-      "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52",   \
-      "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69",   \
-      "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86",   \
-      "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102",       \
-      "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117",  \
-      "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132",  \
-      "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147",  \
-      "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162",  \
-      "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177",  \
-      "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192",  \
-      "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207",  \
-      "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222",  \
-      "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237",  \
-      "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252",  \
-      "a253", "a254", "a255"
-
-#define A4_FENCE() asm volatile("" ::: A4_ALL_AGPRS)
-// accumulator tile (nn, mi) = a[(nn*8 + mi)*4 .. +3]; nn = column tile 0..7 (16 columns each), mi = row tile 0..7
-#define A4_MFMA(NN, MI, WF, AF)                                                                              \
-  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(WF), "v"(AF), "i"(((NN)*8 + (MI)) * 4), \
-               "i"(((NN)*8 + (MI)) * 4 + 3))
-#define A4_MFMA_Z(NN, MI, WF, AF)   /* first K-half of a tile: C = 0, no zeroing pass over the accumulators */     \
-  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(WF), "v"(AF), "i"(((NN)*8 + (MI)) * 4), \
-               "i"(((NN)*8 + (MI)) * 4 + 3))
-template <int IDX>
-__device__ __forceinline__ float a4_acc_read() {
-  float x;
-  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(IDX));
-  return x;
-}
-
-// What a 64-column slice of the wave's tile needs from memory besides the residual: bias / folded bias and LayerNorm
-// column sums.  Slice 0's copy is requested one K-step BEFORE the epilogue (behind the MFMAs of the tile's last K-step),
-// slice 1's at the start of the epilogue - no load latency is exposed for them.  The (rstd, -mean*rstd) pairs of the
-// lane's 8 rows are the same for both slices and are requested first thing in the epilogue.
-struct EpiPre { EpiCols ec; };
-template <int EPI>
-__device__ __forceinline__ void epi_prefetch(const GemmArgs& g, int n0, int ws, int q4, EpiPre& p) {
-  g3_epi_cols<EPI>(g, n0, ws, q4, p.ec);
-  if (epi_has_bias(EPI)) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + ws * 64 + ni * 16 + q4 * 4;
-      p.ec.bias[ni] = *reinterpret_cast<const f32x4*>(g.bias + (n < g.N ? n : 0));
-    }
-  }
-}
-
-// Epilogue of the wave's 128x128 tile held in a[0:255].  The residual tile comes in 16-byte loads in the STORE mapping
-// (4 lanes cover 64 contiguous bytes of a row) through a ring of 8 x 2 registers: all 8 row blocks of slice 0 are
-// requested up front, and as soon as row block mi of slice 0 has consumed its pair it is re-requested for slice 1, so
-// slice 1's residual arrives behind slice 0's arithmetic; v_permlane16_swap (the inverse of the store-side swap) brings
-// it back to the MFMA layout.
-template <int EPI, bool FULL>
-__device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0, int wm, int wn, int l15, int q4,
-                                              const EpiPre& p0) {
-  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first v_accvgpr_read
-#ifdef TSPO_DEV_HOOKS
-  if (g.P <= -10) {   // A/B: the four waves enter the epilogue (-P - 9) x 64 cycles apart instead of in lock-step
-    const int w = wm * 2 + wn;
-    for (int i = 0; i < w * (-g.P - 9); ++i) __builtin_amdgcn_s_sleep(1);
-  }
-#endif
-  constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
-  constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
-  float2 rst[8];
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) rst[mi] = LN ? g3_epi_rowstat(g, m0 + wm * 128 + mi * 16 + l15) : make_float2(1.f, 0.f);
-  EpiPre p1;
-  epi_prefetch<EPI>(g, n0, wn * 2 + 1, q4, p1);
-  uint4 rres[8][2];
-  auto rload = [&](int mi, int ws) {
-    const int m = m0 + wm * 128 + mi * 16 + l15;
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      const int n = n0 + ws * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
-      const bool ok = FULL || (m < g.M && n < g.N);
-      rres[mi][pr] = ok ? *reinterpret_cast<const uint4*>(g.R + (size_t)m * g.N + n) : make_uint4(0u, 0u, 0u, 0u);
-    }
-  };
-  if (RES) {
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) rload(mi, wn * 2);
-  }
-  sfor<0, 2>([&](auto nh_) {                          // the wave's two 64-column slices
-    constexpr int nhs = decltype(nh_)::value;
-    const int ws = wn * 2 + nhs;
-    const EpiPre& p = nhs == 0 ? p0 : p1;
-    sfor<0, 8>([&](auto mi_) {
-      constexpr int mi = decltype(mi_)::value;
-      f32x4 vv[4];
-      sfor<0, 4>([&](auto ni_) {
-        constexpr int ni = decltype(ni_)::value;
-        constexpr int base = ((nhs * 4 + ni) * 8 + mi) * 4;
-        vv[ni][0] = a4_acc_read<base>(); vv[ni][1] = a4_acc_read<base + 1>();
-        vv[ni][2] = a4_acc_read<base + 2>(); vv[ni][3] = a4_acc_read<base + 3>();
-      });
-      A4_FENCE();
-      uint2 rp[4] = {};
-      if (RES) {
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const auto x = __builtin_amdgcn_permlane16_swap(rres[mi][pr].x, rres[mi][pr].z, false, false);
-          const auto y = __builtin_amdgcn_permlane16_swap(rres[mi][pr].y, rres[mi][pr].w, false, false);
-          rp[2 * pr] = make_uint2(x[0], y[0]);
-          rp[2 * pr + 1] = make_uint2(x[1], y[1]);
-        }
-        if (nhs == 0) rload(mi, wn * 2 + 1);
-      }
-#ifdef TSPO_DEV_HOOKS
-      if (nhs == 1 && A7_ABL(g, 3)) {   // ablation: slice 1 computed but not stored (what deferring its stores could save)
-        GemmArgs h = g;
-        h.M = 0;
-        g3_epi_row<EPI, true, false>(h, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
-      } else
-#endif
-      g3_epi_row<EPI, true, FULL>(g, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
-    });
-  });
-}
 
 // A2: A staged two K-steps ahead in two register sets (else one set, one K-step ahead).  PRE0: slice 0's small epilogue
 // inputs are requested behind the tile's last K-step (else at the start of the epilogue).  Both cost VGPRs.
@@ -421,188 +278,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
 }
 
 
-// ===========================================================================
-// "a9": the same tile, wave layout, AGPR accumulators and epilogue as a7, but the operands reach LDS by LDS-DMA
-// (buffer_load_dwordx4 ... lds) in the schedule of the vendor library's hand-written 256x256x64 kernel for this chip
-// (hipBLASLt `Custom_Cijk_Alik_Bljk_BBS_..._MT256x256x64_MI16x16x1`, read from its disassembly as a specification;
-// DESIGN 4.4): the WHOLE K-step's fragments live in registers (4 x 32 VGPRs), so a ring buffer can be refilled two stages
-// ahead as soon as its second K-half has been read into registers - no staging VGPRs, no ds_write, 16 instead of 32 staging
-// instructions per wave and K-step:
-//   K-step it (buffer cb = it & 1 holds stage it, nb stage it+1 in flight, fa0/fw0 = K-half 0 of stage it):
-//     K-half 0 MFMAs | A fragments of K-half 1 <- cb | B1 | DMA A(it+2) -> cb.A, W fragments of K-half 1 <- cb | B2 |
-//                    DMA A(it+2) rest, DMA W(it+2) -> cb.W
-//     K-half 1 MFMAs | DMA W(it+2) | vmcnt(13): stage it+1 landed, B3 | fragments of K-half 0 of stage it+1 <- nb
-// The XOR swizzle of the LDS image (chunk c of row r at c ^ (r & 7)) is applied on the global SOURCE address (an LDS-DMA
-// destination is lane-linear).  DMA instructions are inline asm: hipcc's wait-count pass does not see them, so its own
-// vmcnt waits (epilogue loads / stores) can only over-wait, and the three waits that order DMA against the fragment reads
-// are written here explicitly.
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int tilesM, int ngrp) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE];  // the ONLY LDS object
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, q4 = lane >> 4;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int nk = g.K / GT_BK;   // >= 2
-  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
-  const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
-  const int panels = (tilesM - pset + npset - 1) / npset;
-  const int ntile_x = panels * n_per;
-  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
-  if (my_tiles == 0) return;
-  A4_FENCE();   // claims a[0:255] for this kernel
-
-  // ---- LDS-DMA: piece P = wid*8 + q of a region = rows 8P..8P+7 (1 KB); lane (rin, slot) brings global chunk slot ^ rin ----
-  const int rin = lane >> 3, slot = lane & 7;
-  const unsigned lane_goff = ((unsigned)rin * (unsigned)g.K + (unsigned)((slot ^ rin) << 3)) * 2u;
-  const unsigned piece_stride = 8u * (unsigned)g.K * 2u;
-  const unsigned lds0 = (unsigned)(size_t)lds + (unsigned)wid * 8192u;
-  const unsigned soff0 = (unsigned)wid * 8u * piece_stride;
-  int d_kt = 0, d_s = wl;   // the stage the NEXT K-step's DMA brings: K-step inside the tile, tile
-  auto rsrc_a = [&](int s_) {
-    const int m0 = ((s_ / n_per) * npset + pset) * G3_BM;
-    const long r = m0 < g.M ? ((long)(g.M - m0) * g.K * 2) : 0;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)(m0 < g.M ? m0 : 0) * g.K), 0,
-                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
-  };
-  auto rsrc_w = [&](int s_) {
-    const int n0 = (grp * n_per + s_ % n_per) * G3_BN;
-    const long r = n0 < g.N ? ((long)(g.N - n0) * g.K * 2) : 0;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)(n0 < g.N ? n0 : 0) * g.K), 0,
-                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
-  };
-  __amdgpu_buffer_rsrc_t a_rs = rsrc_a(d_s), w_rs = rsrc_w(d_s);
-  auto adv_d = [&]() {
-    if (++d_kt == nk) {
-      asm volatile("" ::: "memory");   // keeps the tile switch (two divisions, two descriptors) a BRANCH: if-converted it runs every K-step
-      d_kt = 0; d_s += nwl; a_rs = rsrc_a(d_s); w_rs = rsrc_w(d_s);
-    }
-  };
-  auto dma_a = [&](auto q_, int buf) {
-    constexpr int q = decltype(q_)::value;
-    const unsigned dst = lds0 + (unsigned)buf * G3_STAGE + q * 1024u;
-    const unsigned so = soff0 + q * piece_stride + (unsigned)d_kt * (GT_BK * 2u);
-    const unsigned vo = lane_goff;             // (named copies: clang does not capture a variable that only an asm operand uses)
-    const __amdgpu_buffer_rsrc_t rs = a_rs;
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(so) : "memory");
-  };
-  auto dma_w = [&](auto q_, int buf) {
-    constexpr int q = decltype(q_)::value;
-    const unsigned dst = lds0 + (unsigned)buf * G3_STAGE + G3_BM * 128u + q * 1024u;
-    const unsigned so = soff0 + q * piece_stride + (unsigned)d_kt * (GT_BK * 2u);
-    const unsigned vo = lane_goff;
-    const __amdgpu_buffer_rsrc_t rs = w_rs;
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(so) : "memory");
-  };
-
-  // ---- fragments: both K-halves of a stage, A and W: 4 x 8 x 4 VGPRs ----
-  const int sw = l15 & 7;
-  const int fbaseA = (wm * 128 + l15) * 128, fbaseW = G3_BM * 128 + (wn * 128 + l15) * 128;
-  const int co0 = (q4 ^ sw) << 4, co1 = ((4 + q4) ^ sw) << 4;
-  i32x4 fa0[8], fa1[8], fw0[8], fw1[8];
-  auto ldfrag = [&](const char* p) { return *reinterpret_cast<const i32x4*>(p); };
-
-  // ---- prologue: stages 0 and 1 in flight, stage 0 landed, its K-half 0 in registers ----
-  sfor<0, 8>([&](auto q_) { dma_a(q_, 0); dma_w(q_, 0); });
-  adv_d();
-  sfor<0, 8>([&](auto q_) { dma_a(q_, 1); dma_w(q_, 1); });
-  adv_d();
-  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(lds + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(lds + fbaseW + i * 2048 + co0); }
-
-  int it = 0, c_s = wl;
-  auto kstep = [&](auto zero_, auto last_) {
-    constexpr bool ZERO = decltype(zero_)::value, LAST = decltype(last_)::value;
-    const int cb = it & 1;
-    const char* cur = lds + cb * G3_STAGE;
-    const char* nxt = lds + (cb ^ 1) * G3_STAGE;
-    // ---- K-half 0 ----
-    sfor<0, 8>([&](auto nn_) {
-      constexpr int nn = decltype(nn_)::value;
-      sfor<0, 8>([&](auto mi_) {
-        constexpr int mi = decltype(mi_)::value;
-        constexpr int idx = nn * 8 + mi;
-        { const i32x4 wf = fw0[nn], af = fa0[mi]; if (ZERO) A4_MFMA_Z(nn, mi, wf, af); else A4_MFMA(nn, mi, wf, af); }
-        if constexpr (idx < 16 && idx % 2 == 0) fa1[idx / 2] = ldfrag(cur + fbaseA + (idx / 2) * 2048 + co1);
-        if constexpr (idx == 21) {   // B1: every wave holds its A fragments of this stage -> region cb.A may be refilled
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          __builtin_amdgcn_s_waitcnt(0xC07F);
-        }
-        if constexpr (idx >= 22 && idx <= 30 && idx % 2 == 0) dma_a(std::integral_constant<int, (idx - 22) / 2>{}, cb);
-        if constexpr (idx >= 23 && idx <= 31 && idx % 2 == 1) fw1[(idx - 23) / 2] = ldfrag(cur + fbaseW + ((idx - 23) / 2) * 2048 + co1);
-        if constexpr (idx == 33 || idx == 35 || idx == 37) fw1[5 + (idx - 33) / 2] = ldfrag(cur + fbaseW + (5 + (idx - 33) / 2) * 2048 + co1);
-        if constexpr (idx == 47) {   // B2: ... and its W fragments -> cb.W may be refilled
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          __builtin_amdgcn_s_waitcnt(0xC07F);
-        }
-        if constexpr (idx == 48 || idx == 51 || idx == 54) dma_a(std::integral_constant<int, 5 + (idx - 48) / 3>{}, cb);
-        if constexpr (idx == 57 || idx == 60) dma_w(std::integral_constant<int, (idx - 57) / 3>{}, cb);
-      });
-      A4_FENCE();
-    });
-    // ---- K-half 1 ----
-    sfor<0, 8>([&](auto nn_) {
-      constexpr int nn = decltype(nn_)::value;
-      sfor<0, 8>([&](auto mi_) {
-        constexpr int mi = decltype(mi_)::value;
-        constexpr int idx = nn * 8 + mi;
-        { const i32x4 wf = fw1[nn], af = fa1[mi]; A4_MFMA(nn, mi, wf, af); }
-        if constexpr (idx == 2 || idx == 6 || idx == 10) dma_w(std::integral_constant<int, 2 + (idx - 2) / 4>{}, cb);
-        if constexpr (idx == 20) {   // B3: this wave's pieces of stage it+1 have landed (13 younger DMAs may fly) -> everybody's
-          asm volatile("s_waitcnt vmcnt(13)\n\ts_barrier" ::: "memory");
-        }
-        if constexpr (idx == 24) dma_w(std::integral_constant<int, 5>{}, cb);
-        if constexpr (idx == 28) dma_w(std::integral_constant<int, 6>{}, cb);
-        if constexpr (idx == 55) dma_w(std::integral_constant<int, 7>{}, cb);
-        if constexpr (!LAST) {   // K-half 0 of stage it+1 (after a tile's last K-step: behind the epilogue instead)
-          if constexpr (idx == 21 || idx == 22 || idx == 23) fa0[idx - 21] = ldfrag(nxt + fbaseA + (idx - 21) * 2048 + co0);
-          if constexpr (idx == 25 || idx == 26) fa0[idx - 22] = ldfrag(nxt + fbaseA + (idx - 22) * 2048 + co0);
-          if constexpr (idx == 29) fa0[5] = ldfrag(nxt + fbaseA + 5 * 2048 + co0);
-          if constexpr (idx == 31 || idx == 32) fa0[idx - 25] = ldfrag(nxt + fbaseA + (idx - 25) * 2048 + co0);
-          if constexpr (idx == 33 || idx == 34) fw0[idx - 33] = ldfrag(nxt + fbaseW + (idx - 33) * 2048 + co0);
-          if constexpr (idx == 37) fw0[2] = ldfrag(nxt + fbaseW + 2 * 2048 + co0);
-          if constexpr (idx == 40) fw0[3] = ldfrag(nxt + fbaseW + 3 * 2048 + co0);
-          if constexpr (idx == 42) fw0[4] = ldfrag(nxt + fbaseW + 4 * 2048 + co0);
-          if constexpr (idx == 45) fw0[5] = ldfrag(nxt + fbaseW + 5 * 2048 + co0);
-          if constexpr (idx == 48) fw0[6] = ldfrag(nxt + fbaseW + 6 * 2048 + co0);
-          if constexpr (idx == 51) fw0[7] = ldfrag(nxt + fbaseW + 7 * 2048 + co0);
-        }
-      });
-      A4_FENCE();
-    });
-    adv_d();
-    ++it;
-  };
-
-  for (int t = 0; t < my_tiles; ++t) {
-    const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
-    kstep(std::true_type{}, std::false_type{});
-    for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
-    EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
-    epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
-    kstep(std::false_type{}, std::true_type{});
-    if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
-    else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
-    c_s += nwl;
-    const char* nbuf = lds + (it & 1) * G3_STAGE;              // the next tile's first fragments, behind the epilogue
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(nbuf + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(nbuf + fbaseW + i * 2048 + co0); }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two stages requested past the last tile (zero-length resources)
-}
-
-template <int EPI>
-int launch_gemm_a9(GemmArgs g, hipStream_t st) {
-  const int tilesM = (g.M + G3_BM - 1) / G3_BM;
-  g.tilesN = (g.N + G3_BN - 1) / G3_BN;
-  g.nwg = tilesM * g.tilesN;
-  int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
-  if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
-  hipLaunchKernelGGL((gemm_bf16_a9_kernel<EPI>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
-  return tspo::check_launch("gemm_bf16_a9");
-}
-
 template <int EPI, bool A2, bool PRE0, bool RW = false, int DEV = 0>
 int launch_gemm_a7(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
@@ -624,10 +299,6 @@ static void* tspo_dev_debug_ptr() { return g_dev_debug; }
 namespace {
 template <int EPI>
 int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
-  if (g.variant == 77) {
-    if (g.K < 2 * GT_BK) return tspo::set_err(TSPO_EINVAL, "gemm_agpr: K=%d too small for the DMA kernel", g.K);
-    return launch_gemm_a9<EPI>(g, st);
-  }
   if ((g.K / GT_BK) % 2 != 0 || g.K < 2 * GT_BK)
     return tspo::set_err(TSPO_EINVAL, "gemm_agpr: K=%d must be a multiple of 128", g.K);
 #ifdef TSPO_DEV_HOOKS

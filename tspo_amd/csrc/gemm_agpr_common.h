@@ -1,0 +1,152 @@
+// Internal: what the 4-wave kernels that keep their 256 accumulators per lane in AGPRs share (gemm_agpr.hip: register-staged
+// operands; gemm_dma.hip: LDS-DMA operands): literal-AGPR MFMA statements, the compiler fence, and the epilogue out of a[0:255].
+#pragma once
+#include "gemm_epilogue.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// Development hooks (python -m tspo_amd.build --dev only): epilogue ablations selected at run time through GemmArgs.P and
+// an s_memtime probe of the tile phases (DEV bit 0 of the kernel template).  The shipped library compiles none of it.
+#ifdef TSPO_DEV_HOOKS
+#define A7_ABL(g, n) ((g).P == -(n))
+#else
+#define A7_ABL(g, n) false
+#endif
+
+namespace {
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(static_cast<F&&>(f));
+  }
+}
+
+#define A4_ALL_AGPRS                                                                                                     \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18",  \
+      "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35",   \
+      "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52",   \
+      "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69",   \
+      "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86",   \
+      "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102",       \
+      "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117",  \
+      "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132",  \
+      "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147",  \
+      "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162",  \
+      "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177",  \
+      "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192",  \
+      "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207",  \
+      "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222",  \
+      "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237",  \
+      "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252",  \
+      "a253", "a254", "a255"
+
+#define A4_FENCE() asm volatile("" ::: A4_ALL_AGPRS)
+// accumulator tile (nn, mi) = a[(nn*8 + mi)*4 .. +3]; nn = column tile 0..7 (16 columns each), mi = row tile 0..7
+#define A4_MFMA(NN, MI, WF, AF)                                                                              \
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(WF), "v"(AF), "i"(((NN)*8 + (MI)) * 4), \
+               "i"(((NN)*8 + (MI)) * 4 + 3))
+#define A4_MFMA_Z(NN, MI, WF, AF)   /* first K-half of a tile: C = 0, no zeroing pass over the accumulators */     \
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(WF), "v"(AF), "i"(((NN)*8 + (MI)) * 4), \
+               "i"(((NN)*8 + (MI)) * 4 + 3))
+template <int IDX>
+__device__ __forceinline__ float a4_acc_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(IDX));
+  return x;
+}
+
+// What a 64-column slice of the wave's tile needs from memory besides the residual: bias / folded bias and LayerNorm
+// column sums.  Slice 0's copy is requested one K-step BEFORE the epilogue (behind the MFMAs of the tile's last K-step),
+// slice 1's at the start of the epilogue - no load latency is exposed for them.  The (rstd, -mean*rstd) pairs of the
+// lane's 8 rows are the same for both slices and are requested first thing in the epilogue.
+struct EpiPre { EpiCols ec; };
+template <int EPI>
+__device__ __forceinline__ void epi_prefetch(const GemmArgs& g, int n0, int ws, int q4, EpiPre& p) {
+  g3_epi_cols<EPI>(g, n0, ws, q4, p.ec);
+  if (epi_has_bias(EPI)) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + ws * 64 + ni * 16 + q4 * 4;
+      p.ec.bias[ni] = *reinterpret_cast<const f32x4*>(g.bias + (n < g.N ? n : 0));
+    }
+  }
+}
+
+// Epilogue of the wave's 128x128 tile held in a[0:255].  The residual tile comes in 16-byte loads in the STORE mapping
+// (4 lanes cover 64 contiguous bytes of a row) through a ring of 8 x 2 registers: all 8 row blocks of slice 0 are
+// requested up front, and as soon as row block mi of slice 0 has consumed its pair it is re-requested for slice 1, so
+// slice 1's residual arrives behind slice 0's arithmetic; v_permlane16_swap (the inverse of the store-side swap) brings
+// it back to the MFMA layout.
+// RACC: the residual was added to the accumulators during the K-loop (gemm_dma.hip) - a residual form then runs the bias form's
+// memory traffic.
+template <int EPI, bool FULL, bool RACC = false>
+__device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0, int wm, int wn, int l15, int q4,
+                                              const EpiPre& p0) {
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first v_accvgpr_read
+#ifdef TSPO_DEV_HOOKS
+  if (g.P <= -10) {   // A/B: the four waves enter the epilogue (-P - 9) x 64 cycles apart instead of in lock-step
+    const int w = wm * 2 + wn;
+    for (int i = 0; i < w * (-g.P - 9); ++i) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
+  constexpr bool RES = (EPI == GE_RESID || EPI == GE_RESID_ST) && !RACC;
+  constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
+  float2 rst[8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) rst[mi] = LN ? g3_epi_rowstat(g, m0 + wm * 128 + mi * 16 + l15) : make_float2(1.f, 0.f);
+  EpiPre p1;
+  epi_prefetch<EPI>(g, n0, wn * 2 + 1, q4, p1);
+  uint4 rres[8][2];
+  auto rload = [&](int mi, int ws) {
+    const int m = m0 + wm * 128 + mi * 16 + l15;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int n = n0 + ws * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
+      const bool ok = FULL || (m < g.M && n < g.N);
+      rres[mi][pr] = ok ? *reinterpret_cast<const uint4*>(g.R + (size_t)m * g.N + n) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  if (RES) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) rload(mi, wn * 2);
+  }
+  sfor<0, 2>([&](auto nh_) {                          // the wave's two 64-column slices
+    constexpr int nhs = decltype(nh_)::value;
+    const int ws = wn * 2 + nhs;
+    const EpiPre& p = nhs == 0 ? p0 : p1;
+    sfor<0, 8>([&](auto mi_) {
+      constexpr int mi = decltype(mi_)::value;
+      f32x4 vv[4];
+      sfor<0, 4>([&](auto ni_) {
+        constexpr int ni = decltype(ni_)::value;
+        constexpr int base = ((nhs * 4 + ni) * 8 + mi) * 4;
+        vv[ni][0] = a4_acc_read<base>(); vv[ni][1] = a4_acc_read<base + 1>();
+        vv[ni][2] = a4_acc_read<base + 2>(); vv[ni][3] = a4_acc_read<base + 3>();
+      });
+      A4_FENCE();
+      uint2 rp[4] = {};
+      if (RES) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const auto x = __builtin_amdgcn_permlane16_swap(rres[mi][pr].x, rres[mi][pr].z, false, false);
+          const auto y = __builtin_amdgcn_permlane16_swap(rres[mi][pr].y, rres[mi][pr].w, false, false);
+          rp[2 * pr] = make_uint2(x[0], y[0]);
+          rp[2 * pr + 1] = make_uint2(x[1], y[1]);
+        }
+        if (nhs == 0) rload(mi, wn * 2 + 1);
+      }
+#ifdef TSPO_DEV_HOOKS
+      if (nhs == 1 && A7_ABL(g, 3)) {   // ablation: slice 1 computed but not stored (what deferring its stores could save)
+        GemmArgs h = g;
+        h.M = 0;
+        g3_epi_row<EPI, true, false, RACC>(h, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
+      } else
+#endif
+      g3_epi_row<EPI, true, FULL, RACC>(g, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
+    });
+  });
+}
+}  // namespace

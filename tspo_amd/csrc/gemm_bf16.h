@@ -28,4 +28,6 @@ int gemm_bf16(int epi, const GemmArgs& g, hipStream_t st);
 bool gemm_bf16_is_big(long M, int N, int K);
 // gemm_agpr.hip: the 4-wave kernels that keep 256 accumulators per lane in AGPRs (g.variant selects the kernel)
 int gemm_bf16_agpr(int epi, const GemmArgs& g, hipStream_t st);
+// gemm_dma.hip: the same tile with LDS-DMA operands (variants 72-77)
+int gemm_bf16_dma(int epi, const GemmArgs& g, hipStream_t st);
 }

@@ -902,8 +902,9 @@ int launch_gemm_w16(GemmArgs g, hipStream_t st) {
 
 #endif  // TSPO_DEV_HOOKS
 
-// kernel used for "big" problems: the 4-wave AGPR kernel of gemm_agpr.hip (82) whenever K is a multiple of 128, else the
-// 8-wave LDS-DMA ring kernel (6).  In --dev builds TSPO_GEMM_VARIANT overrides it (whole-encoder A/B runs); the shipped
+// kernel used for "big" problems: the 4-wave AGPR kernel with LDS-DMA operands of gemm_dma.hip (77; round 4) for every K that
+// is a multiple of 64 and at least 128; the register-staged 4-wave kernel (82, needs K % 128 == 0) and the 8-wave LDS-DMA ring
+// kernel (6) stay selectable.  In --dev builds TSPO_GEMM_VARIANT overrides it (whole-encoder A/B runs); the shipped
 // library reads no environment variables.
 static int default_big_variant(int K) {
 #ifdef TSPO_DEV_HOOKS
@@ -913,7 +914,7 @@ static int default_big_variant(int K) {
   }();
   if (forced) return forced;
 #endif
-  return (K % 128 == 0) ? 82 : 6;
+  return (K % 64 == 0 && K >= 128) ? 77 : 6;
 }
 
 template <int EPI>
@@ -923,7 +924,8 @@ int launch_gemm(GemmArgs g, hipStream_t st) {
   g.variant = v;
   if (v == 1) return launch_gemm_v1<EPI>(g, st);
   if (v == 6) return launch_gemm_p256<EPI, 1, 6>(g, st);     // 8-wave LDS-DMA ring: interleaved DMA issue + L2 prefetch of A 6 K-steps ahead
-  if (v >= 77 && v < 100) return tspo::gemm_bf16_agpr(EPI, g, st);   // 4-wave kernel with AGPR accumulators (gemm_agpr.hip)
+  if (v >= 72 && v < 78) return tspo::gemm_bf16_dma(EPI, g, st);      // 4-wave AGPR kernel, LDS-DMA operands (gemm_dma.hip)
+  if (v >= 78 && v < 100) return tspo::gemm_bf16_agpr(EPI, g, st);   // 4-wave kernel with AGPR accumulators (gemm_agpr.hip)
 #ifdef TSPO_DEV_HOOKS
   // A/B variants and ablations (tools/bench_gemm.py, tools/probe_gemm_wait.py); several compute wrong results on purpose
   if (v == 65) return launch_gemm_p256<EPI, 1, 0>(g, st);    // no L2 prefetch
@@ -968,7 +970,8 @@ int launch_gemm_ln(GemmArgs g, hipStream_t st) {
   if (EPI == GE_RESID_ST ? !g.spart : !(g.lnc && g.rstats))
     return tspo::set_err(TSPO_EINVAL, "gemm: epilogue %d without its statistics pointers", EPI);
   { const int v = g.variant ? g.variant : default_big_variant(g.K);
-    if (v >= 77 && v < 100) { GemmArgs h = g; h.variant = v; return tspo::gemm_bf16_agpr(EPI, h, st); } }
+    if (v >= 72 && v < 78) { GemmArgs h = g; h.variant = v; return tspo::gemm_bf16_dma(EPI, h, st); }
+    if (v >= 78 && v < 100) { GemmArgs h = g; h.variant = v; return tspo::gemm_bf16_agpr(EPI, h, st); } }
   return launch_gemm_p256<EPI, 1, 6>(g, st);
 }
 }  // namespace
