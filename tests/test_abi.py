@@ -92,7 +92,7 @@ def test_agpr_gemm_code_audit(tmp_path, src, kernel):
                            os.path.join(b.CSRC, src), "-o", str(asm)])
     txt = open(asm).read()
     kernels = re.findall(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)\n\.Lfunc_end" % kernel, txt, flags=re.S | re.M)
-    assert len(kernels) == (10 if kernel == "gemm_bf16_a9_kernel" else 8), [k[0] for k in kernels]   # a9: residual forms twice (R in the epilogue / on the matrix pipe)
+    assert len(kernels) == 8, [k[0] for k in kernels]
     for name, body in kernels:
         inasm, bad, m0bad = False, [], []
         blocks, cur = [], []

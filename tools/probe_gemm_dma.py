@@ -18,8 +18,6 @@ for name, N, K, act, resid in [("qkv", 3072, 1024, 0, False), ("out", 1024, 1024
     R = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16) if resid else None
     dbg = torch.zeros(256 * 4 * 12, dtype=torch.int64, device=dev)
     l.tspo_dma_set_debug(C.c_void_p(dbg.data_ptr()))
-    if v == 72 and not resid:
-        continue
     for _ in range(3):
         ops.gemm_bf16(A, W, bias=bias, residual=R, act=act | (v << 8))
     torch.cuda.synchronize()

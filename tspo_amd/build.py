@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, lab: boo
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
-    flags = (["-DTSPO_DEV_HOOKS"] if dev else []) + (["-DTSPO_A9_LAB"] if lab else [])
+    flags = (["-DTSPO_DEV_HOOKS"] if dev else []) + (["-DTSPO_A9_LAB"] if lab else []) + os.environ.get("TSPO_EXTRA_HIPCC_FLAGS", "").split()
 
     def compile_one(s):
         o = os.path.join(CSRC, s.replace(".hip", ".o"))

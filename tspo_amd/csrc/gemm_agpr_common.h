@@ -80,9 +80,7 @@ __device__ __forceinline__ void epi_prefetch(const GemmArgs& g, int n0, int ws, 
 // requested up front, and as soon as row block mi of slice 0 has consumed its pair it is re-requested for slice 1, so
 // slice 1's residual arrives behind slice 0's arithmetic; v_permlane16_swap (the inverse of the store-side swap) brings
 // it back to the MFMA layout.
-// RACC: the residual was added to the accumulators during the K-loop (gemm_dma.hip) - a residual form then runs the bias form's
-// memory traffic.
-template <int EPI, bool FULL, bool RACC = false>
+template <int EPI, bool FULL>
 __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0, int wm, int wn, int l15, int q4,
                                               const EpiPre& p0) {
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first v_accvgpr_read
@@ -92,7 +90,7 @@ __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0,
     for (int i = 0; i < w * (-g.P - 9); ++i) __builtin_amdgcn_s_sleep(1);
   }
 #endif
-  constexpr bool RES = (EPI == GE_RESID || EPI == GE_RESID_ST) && !RACC;
+  constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
   constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
   float2 rst[8];
 #pragma unroll
@@ -142,10 +140,10 @@ __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0,
       if (nhs == 1 && A7_ABL(g, 3)) {   // ablation: slice 1 computed but not stored (what deferring its stores could save)
         GemmArgs h = g;
         h.M = 0;
-        g3_epi_row<EPI, true, false, RACC>(h, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
+        g3_epi_row<EPI, true, false>(h, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
       } else
 #endif
-      g3_epi_row<EPI, true, FULL, RACC>(g, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
+      g3_epi_row<EPI, true, FULL>(g, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
     });
   });
 }

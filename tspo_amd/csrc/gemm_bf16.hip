@@ -907,7 +907,7 @@ int launch_gemm_w16(GemmArgs g, hipStream_t st) {
 // kernel (6) stay selectable.  In --dev builds TSPO_GEMM_VARIANT overrides it (whole-encoder A/B runs); the shipped
 // library reads no environment variables.
 static int default_big_variant(int K) {
-#ifdef TSPO_DEV_HOOKS
+#if defined(TSPO_DEV_HOOKS) || defined(TSPO_A9_LAB)
   static const int forced = [] {
     const char* e = getenv("TSPO_GEMM_VARIANT");
     return e && atoi(e) > 0 ? atoi(e) : 0;

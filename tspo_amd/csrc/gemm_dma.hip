@@ -40,9 +40,7 @@ enum : int {
   OP_DW = 57,
   OP_MDA = 65,   // +j: m0 and DMA in the same gap
   OP_MDW = 73,
-  OP_B1 = 81, OP_B2 = 82, OP_B3 = 83,
-  OP_RL = 84,    // +j: residual fragment j of this K-step <- global memory (only in a tile's first four K-steps, RACC kernels)
-  OP_RM = 92     // +j: its two accumulate-MFMAs against the selection fragments
+  OP_B1 = 81, OP_B2 = 82, OP_B3 = 83
 };
 struct A9Sched {
   signed char op[128];   // gap after MFMA i of the K-step (0-63: K-half 0, 64-127: K-half 1)
@@ -75,17 +73,13 @@ constexpr A9Sched a9_sched(int s) {
     put(85, OP_B3);
     for (int j = 0; j < 8; ++j) { put(86 + 2 * j, OP_RA0 + j); put(102 + 2 * j, OP_RW0 + j); }
     put(91, OP_MDW + 3); put(97, OP_MDW + 4); put(103, OP_MDW + 5); put(109, OP_MDW + 6); put(115, OP_MDW + 7);
-    // residual units (RACC): loads BEFORE the K-step's first DMA (loads return in order, so B3's vmcnt covers them), MFMAs after B3
-    const int rm[8] = {87, 89, 93, 95, 99, 101, 105, 107};
-    for (int j = 0; j < 8; ++j) { put(1 + 2 * j, OP_RL + j); put(rm[j], OP_RM + j); }
   }
   for (int i = 0; i < 128 && t.op[i] != OP_B3; ++i)
     if ((t.op[i] >= OP_DA && t.op[i] < OP_MW) || (t.op[i] >= OP_DW && t.op[i] < OP_MDA) || (t.op[i] >= OP_MDA && t.op[i] < OP_B1)) ++t.vm;
   return t;
 }
 
-// RACC (residual epilogues, K >= 320): C = R + A W^T on the matrix pipe - see the block in front of the tile loop.
-template <int EPI, int SCHED, bool PROBE = false, bool RACC = false>
+template <int EPI, int SCHED, bool PROBE = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int tilesM, int ngrp) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE];  // the ONLY LDS object
   constexpr A9Sched SC = a9_sched(SCHED % 100);
@@ -166,27 +160,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
   for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(lds + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(lds + fbaseW + i * 2048 + co0); }
 
   int it = 0, c_s = wl;
-  // ---- RACC: the residual tile enters the accumulators through the matrix pipe instead of being added in the epilogue, where
-  //      its first-touch load latency sat on the critical path (round-3 probe: residual epilogues 17-20 k cycles, bias forms
-  //      9.4 k).  A 16-row x 32-column piece of R, loaded in the MFMA B-operand layout (lane (row, q4) = 8 consecutive columns,
-  //      one 16-byte load), times a 0/1 selection fragment adds R exactly (1.0 * r, fp32 accumulate) to two 16x16 accumulator
-  //      tiles: D[n][m] += sum_k sel_h[n][k] * R[m][k], sel_h[n][k] = (k == n + 16 h).  32 loads + 64 MFMAs per wave and
-  //      tile (+3 % matrix work at K = 1024), spread over the tile's first four K-steps; no VALU work, no epilogue traffic.
-  i32x4 sel0 = {0, 0, 0, 0}, sel1 = {0, 0, 0, 0}, rr[8];
-  unsigned r_voff = 0;
-  __amdgpu_buffer_rsrc_t r_rs = a_rs;
-  auto r_tile = [&](int m0, int n0) {   // per tile: descriptor from the tile's first row (rows past M read as zeros), lane offset
-    const long r = m0 < g.M ? ((long)(g.M - m0) * g.N * 2) : 0;
-    r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.R + (size_t)(m0 < g.M ? m0 : 0) * g.N), 0,
-                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
-    r_voff = ((unsigned)(wm * 128 + l15) * (unsigned)g.N + (unsigned)(n0 + wn * 128 + q4 * 8)) * 2u;
-  };
-  if (RACC) {
-    const int one = 0x3F80 << (16 * (l15 & 1)), d = (l15 & 7) >> 1;
-    const bool h0 = q4 == (l15 >> 3), h1 = q4 == (l15 >> 3) + 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { sel0[i] = (h0 && d == i) ? one : 0; sel1[i] = (h1 && d == i) ? one : 0; }
-  }
   // PROBE (dev builds): s_memtime cycles per K-step and inside each synchronisation point, summed per wave
   unsigned long long pr_ks = 0, pr_n = 0, pr_b1 = 0, pr_b2 = 0, pr_vm = 0, pr_b3 = 0, pr_vmz = 0, pr_nz = 0, pr_vm1 = 0, pr_epi = 0, pr_tile = 0;
   int pr_kt = 0;
@@ -195,9 +168,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
     if (PROBE) { t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     return t;
   };
-  auto kstep = [&](auto zero_, auto last_, auto rk_) {
+  auto kstep = [&](auto zero_, auto last_) {
     constexpr bool ZERO = decltype(zero_)::value, LAST = decltype(last_)::value;
-    constexpr int RK = decltype(rk_)::value;   // 0-3: this K-step carries residual units 8 RK .. 8 RK + 7 (row tiles 2 RK, 2 RK + 1); -1: none
     const int cb = it & 1;
     const unsigned long long pr_t0 = stamp();
     const char* cur = lds + cb * G3_STAGE;
@@ -229,18 +201,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
           set_m0(std::integral_constant<int, op - OP_MDW>{}, std::true_type{}, bb);
           dma(std::integral_constant<int, op - OP_MDW>{}, std::true_type{}, vo);
         }
-        if constexpr (RACC && RK >= 0 && op >= OP_RL && op < OP_RL + 8) {
-          constexpr int j = op - OP_RL, rmi = 2 * RK + (j >> 2), rcb = j & 3;
-          const unsigned rvo = r_voff, rso = (unsigned)(rmi * 32) * (unsigned)g.N + rcb * 64u;
-          const __amdgpu_buffer_rsrc_t rs = r_rs;
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rr[j]) : "v"(rvo), "s"(rs), "s"(rso) : "memory");
-        }
-        if constexpr (RACC && RK >= 0 && op >= OP_RM && op < OP_RM + 8) {
-          constexpr int j = op - OP_RM, rmi = 2 * RK + (j >> 2), rcb = j & 3;
-          const i32x4 s0 = sel0, s1 = sel1, rf = rr[j];
-          A4_MFMA(2 * rcb, rmi, s0, rf);
-          A4_MFMA(2 * rcb + 1, rmi, s1, rf);
-        }
         if constexpr (op == OP_B1 || op == OP_B2) {   // every wave holds its A (B1) / W (B2) fragments of this stage -> region may be refilled
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           const unsigned long long ta = stamp();
@@ -269,25 +229,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
 
   for (int t = 0; t < my_tiles; ++t) {
     const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
-    using NoR = std::integral_constant<int, -1>;
     const unsigned long long pr_tt0 = stamp();
-    if (RACC) {   // nk >= 5 (launcher)
-      r_tile(m0, n0);
-      kstep(std::true_type{}, std::false_type{}, std::integral_constant<int, 0>{});
-      kstep(std::false_type{}, std::false_type{}, std::integral_constant<int, 1>{});
-      kstep(std::false_type{}, std::false_type{}, std::integral_constant<int, 2>{});
-      kstep(std::false_type{}, std::false_type{}, std::integral_constant<int, 3>{});
-      for (int kt = 4; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{}, NoR{});
-    } else {
-      kstep(std::true_type{}, std::false_type{}, NoR{});
-      for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{}, NoR{});
-    }
+    kstep(std::true_type{}, std::false_type{});
+    for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
     EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
     epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
-    kstep(std::false_type{}, std::true_type{}, NoR{});
+    kstep(std::false_type{}, std::true_type{});
     const unsigned long long pr_te0 = stamp();
-    if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true, RACC>(g, m0, n0, wm, wn, l15, q4, p0);
-    else agpr_epilogue<EPI, false, RACC>(g, m0, n0, wm, wn, l15, q4, p0);
+    if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
+    else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
     if (PROBE) pr_epi += stamp() - pr_te0;
     c_s += nwl;
     const char* nbuf = lds + (it & 1) * G3_STAGE;              // the next tile's first fragments, behind the epilogue
@@ -303,14 +253,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
   }
 }
 
-template <int EPI, int SCHED, bool PROBE = false, bool RACC = false>
+template <int EPI, int SCHED, bool PROBE = false>
 int launch_gemm_a9(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
   g.tilesN = (g.N + G3_BN - 1) / G3_BN;
   g.nwg = tilesM * g.tilesN;
   int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
   if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
-  hipLaunchKernelGGL((gemm_bf16_a9_kernel<EPI, SCHED, PROBE, RACC>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
+  hipLaunchKernelGGL((gemm_bf16_a9_kernel<EPI, SCHED, PROBE>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
   return tspo::check_launch("gemm_bf16_a9");
 }
 
@@ -318,12 +268,7 @@ int launch_gemm_a9(GemmArgs g, hipStream_t st) {
 template <int EPI>
 int launch_a9_variant(const GemmArgs& g, hipStream_t st) {
   if (g.K < 2 * GT_BK) return tspo::set_err(TSPO_EINVAL, "gemm_dma: K=%d too small for the DMA kernel", g.K);
-  if (g.variant == 77) {   // production schedule; residual forms add R on the matrix pipe when the tile has K-steps to spread it over
-    if constexpr (EPI == GE_RESID || EPI == GE_RESID_ST)
-      if (g.K >= 5 * GT_BK) return launch_gemm_a9<EPI, 4, false, true>(g, st);
-    return launch_gemm_a9<EPI, 4>(g, st);
-  }
-  if (g.variant == 73) return launch_gemm_a9<EPI, 4>(g, st);   // A/B: residual forms with the residual added in the epilogue
+  if (g.variant == 77) return launch_gemm_a9<EPI, 4>(g, st);   // production schedule
 #ifdef TSPO_A9_LAB
   if constexpr (EPI == GE_BIAS || EPI == GE_GELU || EPI == GE_RESID) {   // schedule A/Bs: the micro-benchmark's epilogues only
     if (g.variant == 76) return launch_gemm_a9<EPI, 0>(g, st);     // the vendor kernel's positions
@@ -334,13 +279,6 @@ int launch_a9_variant(const GemmArgs& g, hipStream_t st) {
       if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_dma: probe variant without a debug buffer");
       return launch_gemm_a9<EPI, 4, true>(h, st);
     }
-    if constexpr (EPI == GE_RESID)
-      if (g.variant == 72) {                                       // ... with the residual on the matrix pipe
-        GemmArgs h = g;
-        h.pos = reinterpret_cast<const float*>(g_dma_debug);
-        if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_dma: probe variant without a debug buffer");
-        return launch_gemm_a9<EPI, 4, true, true>(h, st);
-      }
   }
 #endif
   return tspo::set_err(TSPO_EINVAL, "gemm: kernel variant %d (epilogue %d) is not part of this build", g.variant, EPI);

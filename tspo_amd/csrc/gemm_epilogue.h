@@ -45,12 +45,11 @@ __device__ __forceinline__ float2 g3_epi_rowstat(const GemmArgs& g, int m) {   /
 // PRE: bias / folded bias comes from ec.bias and the residual from rpre[ni] (this lane's 4 bf16 of column tile ni, MFMA
 // layout) - both fetched by the caller ahead of time - instead of being loaded here.
 // FULL: the caller guarantees that the whole 256x256 tile lies inside the matrix (no per-element range predicates).
-// NORES: a residual epilogue whose residual is already in the accumulators (gemm_dma.hip adds it on the matrix pipe).
-template <int EPI, bool PRE = false, bool FULL = false, bool NORES = false>
+template <int EPI, bool PRE = false, bool FULL = false>
 __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], const EpiCols& ec, float2 rst, int m, int n0,
                                            int wn, int q4, const float* lbias, const uint2* rpre = nullptr) {
   constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
-  constexpr bool RES = (EPI == GE_RESID || EPI == GE_RESID_ST) && !NORES;
+  constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
   size_t orow = (size_t)m;
   int prow = 0;
   if (EPI == GE_PATCH) {
