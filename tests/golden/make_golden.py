@@ -397,15 +397,64 @@ def gen_glue(_out):
     print(f"glue: -> {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+PUBLISHED = [("LongVideoBench", "id", "lvb_val"), ("MLVU", "question_id", "mlvu"), ("VideoMME", "question_id", "videomme")]
+
+
+def gen_published(_out):
+    """The reference-held published outputs at the frame-index boundary (evaluation/jsons_idx/TSPO_*_frameIdx.json, read by
+    lmms-eval llava_vid_tspo.py:362-380; written by mp_tools/change_score_tch.py:22-44 from evaluation/jsons/*.json): per-file
+    invariants plus a deterministic sample of whole docs -> tests/golden/published.json.  They cannot be REPRODUCED offline (no
+    weights, no videos); they pin the formats: join keys, float frame numbers, ascending order, the short-video branch."""
+    import hashlib
+    import json
+    import math
+    g = {}
+    for ds, key, anno_name in PUBLISHED:
+        path = f"/root/reference/evaluation/jsons_idx/TSPO_{ds}_frameIdx.json"
+        text = open(path).read()
+        docs = json.loads(text)
+        anno = json.load(open(f"/root/reference/evaluation/jsons/{anno_name}.json"))
+        assert text == json.dumps(docs) and len(anno) == len(docs)
+        assert all(list(d)[-1] == "frame_idx" for d in docs)                 # the join appends the field (change_score_tch.py:42)
+        assert all({k: v for k, v in d.items() if k != "frame_idx"} == a for d, a in zip(docs, anno))
+        lens = [len(d["frame_idx"]) for d in docs]
+
+        def step_of(f):
+            s = 0
+            for v in f:
+                s = math.gcd(s, int(v))
+            return s
+        short = [i for i, d in enumerate(docs) if len(d["frame_idx"]) < 64]
+        slow = [i for i, d in enumerate(docs) if len(d["frame_idx"]) == 64 and step_of(d["frame_idx"]) == 1]
+        pick = sorted(set([0, 1] + [len(docs) * j // 7 for j in range(1, 7)] + short[:3] + slow[:2]))
+        g[ds] = {
+            "join_key": key, "anno_file": anno_name, "n_docs": len(docs), "sha256": hashlib.sha256(text.encode()).hexdigest(),
+            "bytes": len(text), "distinct_keys": len({d[key] for d in docs}),
+            "n_with_64": sum(n == 64 for n in lens), "n_short": len(short), "max_len": max(lens), "min_len": min(lens),
+            "all_ascending": all(d["frame_idx"] == sorted(d["frame_idx"]) for d in docs),
+            "all_distinct": all(len(set(d["frame_idx"])) == len(d["frame_idx"]) for d in docs),
+            "all_float_integers": all(isinstance(v, float) and v.is_integer() for d in docs for v in d["frame_idx"]),
+            # a doc shorter than 64 entries lists EVERY 1-fps candidate 0, s, 2s, ... (gen_id_tspo.py:83-92: no selection when T <= 64)
+            "short_docs_are_all_candidates": all(
+                [int(v) for v in docs[i]["frame_idx"]] == [j * int(docs[i]["frame_idx"][1] - docs[i]["frame_idx"][0])
+                                                           for j in range(len(docs[i]["frame_idx"]))] for i in short),
+            "sample_positions": pick, "sample_docs": [docs[i] for i in pick],
+        }
+    path = os.path.join(HERE, "published.json")
+    with open(path, "w") as f:
+        json.dump(g, f, indent=0)
+    print(f"published: -> {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 def main():
     groups = {"selector": gen_selector, "misc": gen_misc, "gumbel": gen_gumbel, "train": gen_train, "clip": gen_clip,
-              "glue": gen_glue}
+              "glue": gen_glue, "published": gen_published}
     which = sys.argv[1:] or list(groups)
     for g in which:
         out = {}
         groups[g](out)
-        if g == "glue":
-            continue          # writes glue.json itself (strings, nested lists)
+        if g in ("glue", "published"):
+            continue          # write their own JSON files (strings, nested lists)
         path = os.path.join(HERE, f"{g}.npz")
         np.savez_compressed(path, **out)
         print(f"{g}: {len(out)} arrays -> {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
