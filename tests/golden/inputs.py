@@ -54,3 +54,48 @@ def clip_pixels(cfg, n_frames):
     mean = np.array([0.48145466, 0.4578275, 0.40821073], np.float32).reshape(1, 3, 1, 1)
     std = np.array([0.26862954, 0.26130258, 0.27577711], np.float32).reshape(1, 3, 1, 1)
     return u8, ((u8.astype(np.float32) / 255.0 - mean) / std).astype(np.float32)
+
+
+# ---- scenarios shared by tests/test_gpu_ops.py / test_gpu_e2e.py (HIP vs fp32 oracle) and make_golden.py's `noise` group
+#      (the reference's own bf16 path vs fp32 on the SAME pixels / weights / text): name -> (weights, frames, pixel seed) ----
+ENCODE_SCENARIOS = {"l14_normal_70": ("normal", 70, 4321), "l14_heavy_64": ("heavy_tailed", 64, 777)}
+E2E_SCENARIOS = {"normal": ("normal", 128, [9, 10, 40, 41, 42, 77, 100, 101]), "heavy_tailed": ("heavy_tailed", 64, [9, 10, 40, 41])}
+E2E_TAU, E2E_WINDOW, E2E_TEXT_SEED = 0.025, 12, 4242
+
+
+def clip_l14_state(weights):
+    return synth.clip_vision_state(**synth.CLIP_L14) if weights == "normal" else synth.clip_vision_state_heavy_tailed(synth.CLIP_L14)
+
+
+def e2e_video(n, needles, seed):
+    """n frames of 224x224 'block images' (16x16 random colour blocks, upsampled x14: frames differ strongly, like
+    shots of a video); the `needles` frames all show ONE scene (same blocks, +-6 grey levels of per-pixel noise)."""
+    blocks = synth.uniform_u8((n, 3, 16, 16), seed).astype(np.int16)
+    scene = synth.uniform_u8((3, 16, 16), seed + 1).astype(np.int16)
+    for j in needles:
+        blocks[j] = scene
+    frames = np.repeat(np.repeat(blocks, 14, axis=2), 14, axis=3)
+    noise = (synth.uniform_u8((n, 3, 224, 224), seed + 2).astype(np.int16) % 13) - 6
+    return np.clip(frames + noise, 0, 255).astype(np.uint8)
+
+
+def e2e_selector_state():
+    return synth.selector_state(768, seed=5, std=0.02)
+
+
+def e2e_independent_text(i=0):
+    return synth.normal((1, 768), E2E_TEXT_SEED + i)
+
+
+def e2e_texts(f32, needles):
+    """The text features the end-to-end score error is measured on (one sample of it is a draw from a wide distribution:
+    the error a feature perturbation makes in cos(text, frame) depends on the text's direction): the planted-scene query
+    (what distinguishes the needle frames from the average frame, as in the index-parity test), the same for half of the
+    needles, and four independent N(0,1) vectors.  f32: fp32 features [n, 768] of the side that builds them."""
+    import torch
+    def planted(ids):
+        return torch.nn.functional.normalize(f32[ids].mean(0, keepdim=True) - f32.mean(0, keepdim=True), dim=-1)
+    out = {"planted": planted(list(needles)), "planted_half": planted(list(needles)[: max(1, len(needles) // 2)])}
+    for i in range(4):
+        out[f"independent_{i}"] = torch.from_numpy(e2e_independent_text(i))
+    return out

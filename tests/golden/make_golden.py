@@ -391,6 +391,19 @@ def gen_glue(_out):
                       "sampled": {"pick": pick, "frames": fs.tolist(), "frame_time": fts, "video_time": vts},
                       "from_index": idx_plans})
     g["frame_plans"] = plans
+
+    # ---- the partition helper of adaptive keyframe sampling (model/utils.py:83-126), its own function body ----
+    import heapq as _heapq
+    ns4 = _ref_functions("model/utils.py", ["meanstd"], {"np": np, "heapq": _heapq})
+    ms = []
+    for T, n, t1, depth, seed in [(64, 8, 0.2, 3, 11), (300, 16, 0.2, 3, 12), (97, 8, 0.05, 4, 13), (40, 8, 0.5, 2, 14), (128, 32, 0.2, 5, 15)]:
+        sc = synth.uniform((T,), 700 + seed).astype(np.float64)
+        sc[::7] = sc[0]                                               # ties
+        z = (sc - sc.min()) / (sc.max() - sc.min())
+        a, b = ns4["meanstd"](T, [dict(score=z, depth=0)], n, [list(range(T))], t1, -100, depth)
+        ms.append({"T": T, "n": n, "t1": t1, "all_depth": depth, "seed": 700 + seed, "depths": [x["depth"] for x in a],
+                   "frames": [[int(v) for v in f] for f in b]})
+    g["meanstd"] = ms
     path = os.path.join(HERE, "glue.json")
     with open(path, "w") as f:
         json.dump(g, f, indent=0)
@@ -446,14 +459,113 @@ def gen_published(_out):
     print(f"published: -> {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+def gen_noise(_out):
+    """How far the REFERENCE'S OWN precision sits from fp32 (the reference runs CLIP and the scoring head in bf16:
+    mp_tools/vlmeval/vlm/gen_id_tspo.py:55, src/open_tspo/trainer/tspo_trainer.py:201): the installed transformers CLIP and the
+    imported MultiModal_Align, cast to torch.bfloat16 exactly as `from_pretrained(torch_dtype=torch.bfloat16)` does, run on the
+    CPU on the SAME weights / pixels / text as the HIP-vs-oracle tests (tests/golden/inputs.py: ENCODE_SCENARIOS, E2E_SCENARIOS).
+    The fp32 side carries the bf16-ROUNDED parameters (what both the bf16 model and the HIP encoder hold), so the deltas are
+    arithmetic noise only.  Stored: feature error as a fraction of the fp32 feature range, the smallest per-frame cosine, the
+    score error in logits, and how many of the reference's own bf16 top-k indices differ from its fp32 ones.  The HIP
+    tolerances are tied to these (tests assert HIP-vs-fp32 <= 1.5 x) -> tests/golden/bf16_noise.json.  ~15 min of CPU."""
+    import json
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from transformers.image_utils import OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
+    from inputs import (ENCODE_SCENARIOS, E2E_SCENARIOS, E2E_TAU, E2E_WINDOW, clip_l14_state, e2e_video, e2e_selector_state,
+                        e2e_texts)
+    g = {"clip": {}, "selector": {}, "encode": {}, "e2e": {}}
+    tspo_like = TSPOModel.inference_ts
+    only_e2e = os.environ.get("TSPO_NOISE_ONLY_E2E") == "1"     # regenerate the end-to-end group only, keep the rest of the file
+    if only_e2e:
+        g = json.load(open(os.path.join(HERE, "bf16_noise.json")))
+        g["e2e"] = {}
+
+    def clip_model(cfgd, state):
+        cfg = CLIPVisionConfig(hidden_size=cfgd["hidden"], intermediate_size=cfgd["mlp"], num_hidden_layers=cfgd["layers"],
+                               num_attention_heads=cfgd["heads"], image_size=cfgd["image"], patch_size=cfgd["patch"],
+                               projection_dim=cfgd["proj"], hidden_act="quick_gelu", layer_norm_eps=1e-5, attn_implementation="eager")
+        model = CLIPVisionModelWithProjection(cfg).eval()
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
+        return model.to(torch.bfloat16)          # parameters rounded once; .float() below keeps the rounded values
+
+    def both(model, px):
+        out32, out16 = [], []
+        with torch.no_grad():
+            for i in range(0, px.shape[0], 16):
+                out16.append(model(pixel_values=px[i:i + 16].to(torch.bfloat16)).image_embeds.float())
+            model.float()
+            for i in range(0, px.shape[0], 16):
+                out32.append(model(pixel_values=px[i:i + 16]).image_embeds)
+        return torch.cat(out32), torch.cat(out16)
+
+    def stats(f32, f16):
+        cos = torch.nn.functional.cosine_similarity(f32, f16, dim=-1)
+        return {"err_over_range": float((f16 - f32).abs().max() / f32.abs().max()), "min_cos": float(cos.min()),
+                "range": float(f32.abs().max())}
+
+    def normalize_u8(u8):
+        m = torch.tensor(OPENAI_CLIP_MEAN).view(1, 3, 1, 1)
+        sd = torch.tensor(OPENAI_CLIP_STD).view(1, 3, 1, 1)
+        return (torch.from_numpy(u8).float() / 255.0 - m) / sd
+
+    def head_noise(f32, f16, txt, sel):
+        cs = torch.nn.CosineSimilarity(dim=-1)
+        with torch.no_grad():
+            s32, _ = ref_selector(768, 8, sel)(f32, txt, cs(txt, f32), window_size=E2E_WINDOW, score_tau=E2E_TAU)
+            m16 = ref_selector(768, 8, sel).to(torch.bfloat16)
+            f16b, t16 = f16.to(torch.bfloat16), txt.to(torch.bfloat16)
+            s16, _ = m16(f16b, t16, cs(t16, f16b), window_size=E2E_WINDOW, score_tau=E2E_TAU)
+        s16 = s16.float()
+        eps = float((s16 - s32).abs().max())
+        r = {"score_eps_logits": eps, "score_eps_cosine_units": eps * E2E_TAU, "score_spread_logits": float(s32.max() - s32.min())}
+        for k in (8, 32):
+            a = quiet(tspo_like, None, s32, "topk", k)[0].tolist()
+            b = quiet(tspo_like, None, s16, "topk", k)[0].tolist()
+            r[f"top{k}_overlap_bf16_vs_fp32"] = len(set(a) & set(b))
+        return r
+
+    # small models: the golden CLIP cases
+    for tag, cfgd, n in ([] if only_e2e else CLIP_CASES[:2]):
+        for wname, state in (("normal", synth.clip_vision_state(**cfgd)), ("heavy_tailed", synth.clip_vision_state_heavy_tailed(cfgd))):
+            f32, f16 = both(clip_model(cfgd, state), torch.from_numpy(clip_pixels(cfgd, n)[1]))
+            g["clip"][f"{tag}.{wname}"] = dict(stats(f32, f16), frames=n)
+            print(tag, wname, g["clip"][f"{tag}.{wname}"], flush=True)
+    # CLIP-L/14 on the pixels of the HIP encode tests
+    for name, (wname, n, seed) in ({} if only_e2e else ENCODE_SCENARIOS).items():
+        f32, f16 = both(clip_model(synth.CLIP_L14, clip_l14_state(wname)), normalize_u8(synth.uniform_u8((n, 3, 224, 224), seed)))
+        g["encode"][name] = dict(stats(f32, f16), frames=n)
+        print("encode", name, g["encode"][name], flush=True)
+    # the whole pipeline (bf16 encode -> bf16 scoring head) on the end-to-end test's videos, planted-scene and independent text
+    sel = e2e_selector_state()
+    for name, (wname, n, needles) in E2E_SCENARIOS.items():
+        f32, f16 = both(clip_model(synth.CLIP_L14, clip_l14_state(wname)), normalize_u8(e2e_video(n, needles, 1000 + n)))
+        per_text = {tn: head_noise(f32, f16, tx, sel) for tn, tx in e2e_texts(f32, needles).items()}
+        g["e2e"][name] = {"frames": n, "tau": E2E_TAU, "features": stats(f32, f16), "texts": per_text,
+                          "max_score_eps_logits": max(v["score_eps_logits"] for v in per_text.values())}
+        print("e2e", name, g["e2e"][name], flush=True)
+    for name, T, D, H, w, tau, M, ks in ([] if only_e2e else SELECTOR_CASES):
+        img, txt, clip, state = selector_inputs(name, T, D, M)
+        with torch.no_grad():
+            s32, _ = ref_selector(D, H, state)(torch.from_numpy(img), torch.from_numpy(txt), torch.from_numpy(clip), window_size=w, score_tau=tau)
+            m16 = ref_selector(D, H, state).to(torch.bfloat16)
+            s16, _ = m16(torch.from_numpy(img).to(torch.bfloat16), torch.from_numpy(txt).to(torch.bfloat16),
+                         torch.from_numpy(clip).to(torch.bfloat16), window_size=w, score_tau=tau)
+        eps = float((s16.float() - s32).abs().max())
+        g["selector"][name] = {"T": T, "D": D, "tau": tau, "score_eps_logits": eps, "score_eps_over_absmax": eps / float(s32.abs().max())}
+    path = os.path.join(HERE, "bf16_noise.json")
+    with open(path, "w") as f:
+        json.dump(g, f, indent=1)
+    print(f"noise: -> {path}")
+
+
 def main():
     groups = {"selector": gen_selector, "misc": gen_misc, "gumbel": gen_gumbel, "train": gen_train, "clip": gen_clip,
-              "glue": gen_glue, "published": gen_published}
+              "glue": gen_glue, "published": gen_published, "noise": gen_noise}
     which = sys.argv[1:] or list(groups)
     for g in which:
         out = {}
         groups[g](out)
-        if g in ("glue", "published"):
+        if g in ("glue", "published", "noise"):
             continue          # write their own JSON files (strings, nested lists)
         path = os.path.join(HERE, f"{g}.npz")
         np.savez_compressed(path, **out)

@@ -275,3 +275,61 @@ def test_train_cli_self_spawns_two_ranks(tmp_path):
     assert [l["step"] for l in logged] == [1, 2]
     assert sorted(d for d in os.listdir(out) if d.startswith("checkpoint-")) == ["checkpoint-1", "checkpoint-2"]
     assert os.path.exists(os.path.join(out, "checkpoint-2", "model.safetensors"))
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_hanging():
+    """`python bench.py --gpus 2` on a box with ONE visible GPU (no --same-device): a clear message and a non-zero exit code
+    at once - not a rendezvous that waits for a rank that can never get a device (what the first real N > 1 run must not do
+    when a node comes up with fewer GPUs than asked for)."""
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one visible GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2 but only 1 GPU(s) visible" in r.stderr and not _json_lines(r.stdout)
+
+
+def test_self_spawn_quotes_the_failing_ranks_stderr(tmp_path):
+    """A rank that dies takes the others down and the launcher's own message carries the tail of ITS stderr."""
+    from tspo_amd import dist as tdist
+    prog = tmp_path / "prog.py"
+    prog.write_text("import os, sys, time\n"
+                    "if os.environ['RANK'] == '1':\n"
+                    "    sys.stderr.write('rank one says: no device\\n'); sys.exit(7)\n"
+                    "time.sleep(60)\n")
+    code = ("import sys; sys.path.insert(0, %r); from tspo_amd import dist as d; sys.exit(d.self_spawn(2, [%r], timeout=50))"
+            % (ROOT, str(prog)))
+    r = subprocess.run([sys.executable, "-c", code], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7
+    assert "rank 1 of 2 exited with code 7" in r.stderr and "rank one says: no device" in r.stderr.split("Last lines of its stderr")[-1]
+
+
+def test_bench_line_explains_itself_and_times_the_dp_path():
+    """The default single-GPU bench line (short run): per-step spread, the clock / power sampled during the timed steps with the
+    roofline fraction at that clock, and `rollouts_dp_path` - the reference's own training configuration (one prompt per
+    micro-step, two micro-steps, the bucket all-reduce really issued on a live one-rank RCCL group) with its launch count."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-pruned", "--no-720p"], env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in _json_lines(r.stdout) if "metric" in l][0]
+    assert line["ms_per_step_min"] <= line["ms_per_step_median"] <= line["ms_per_step_max"]
+    assert abs(line["ms_per_step_median"] - line["ms_per_step"]) < 0.2 * line["ms_per_step"]
+    roof = line["roofline"]
+    assert roof["kernel"] == "gemm_bf16_a9_kernel" and 0.3 < roof["frac"] < 0.7
+    assert roof["gpu_state"]["samples"] > 0, roof["gpu_state"]
+    assert 500 < roof["sclk_mhz"] <= 2400 and 100 < roof["power_w"] < 2000
+    assert roof["frac_at_sustained_clock"] >= roof["frac"] - 1e-6
+    assert "fused single-rank" in line["rollouts_variant"]
+    dp = line["rollouts_dp_path"]
+    assert "error" not in dp, dp
+    assert dp["config"] == {"prompts_per_micro_step": 1, "grad_accum_steps": 2, "T": 512, "G": 8, "k": 16, "ranks": 1}
+    assert dp["rollouts_per_s"] > 0 and "1-rank process group" in dp["allreduce"]
+    by = dp["launches_by_kernel"]
+    assert by is not None and dp["launches_per_optimizer_step"] == round(sum(by.values()))
+    # (a one-rank RCCL all-reduce is a device copy, which the launch count leaves out like every memcpy; `comm` below shows the
+    # group the step's reduce_fn ran on)
+    assert by.get("adamw_clip_kernel") == 1.0 and by.get("gumbel_topk_kernel") == 2.0       # one update, two micro-steps
+    assert dp["launches_per_optimizer_step"] <= 31          # 2 x 14 micro-step kernels + add_ of the second micro-batch + norm + AdamW
+    comm = line["comm"]
+    assert comm["world"] == 1 and comm["backend"] == "nccl" and comm["sum_correct"] and comm["distinct_devices"] == 1
+    assert comm["ranks"][0]["pci"] == roof["gpu_state"]["pci"]

@@ -61,8 +61,13 @@ GPU_SIZES = SIZES + [(720, 1280), (433, 577), (224, 1000), (2160, 3840)]    # + 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["matrix", "lds"])
 @pytest.mark.parametrize("hw", GPU_SIZES, ids=[f"{h}x{w}" for h, w in GPU_SIZES])
-def test_gpu_preprocess_bit_exact(hw):
+def test_gpu_preprocess_bit_exact(hw, path, monkeypatch):
+    """Bit-exact against the Pillow-pinned oracle through BOTH horizontal passes the C ABI can take at out_w = 224: the
+    matrix-pipe kernel (tspo_preprocess_frames_ex with the digit-split tap matrices, the default) and the LDS-staged scalar kernel
+    (what tspo_preprocess_frames - no matrix tables - and spans beyond 4 K-blocks run)."""
+    monkeypatch.setattr(P, "USE_MATRIX_PASS", path == "matrix")
     H, W = hw
     T = 3 if H * W < 2000 * 2000 else 1
     frames = synth.uniform_u8((T, H, W, 3), 55 + H + W)
@@ -78,6 +83,21 @@ def test_gpu_preprocess_bit_exact(hw):
         view.copy_(torch.from_numpy(frames).cuda())
         assert view.data_ptr() % 4 == off
         np.testing.assert_array_equal(P.preprocess_frames(view).cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,size", [((97, 131), 222), ((360, 640), 222), ((720, 1280), 98), ((300, 224), 222), ((222, 222), 222)],
+                         ids=["97x131->222", "360x640->222", "720p->98", "300x224->222", "identity-222"])
+def test_gpu_preprocess_plain_scalar_fallback(hw, size):
+    """An output width that is not a multiple of 4 (dword-aligned rows are what the LDS-staged and matrix passes need) takes
+    the byte-granular kernels of round 2 - the path for odd sizes and misaligned caller buffers: same bit-exactness, both
+    input layouts, including a pure crop (identity resize)."""
+    H, W = hw
+    frames = synth.uniform_u8((2, H, W, 3), 91 + H + W + size)
+    ref = O.clip_preprocess_u8(frames, size=size)
+    np.testing.assert_array_equal(P.preprocess_frames(torch.from_numpy(frames).cuda(), size=size).cpu().numpy(), ref)
+    chw = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 3, 1, 2))).cuda()
+    np.testing.assert_array_equal(P.preprocess_frames(chw, size=size).cpu().numpy(), ref)
 
 
 @pytest.mark.gpu

@@ -334,12 +334,13 @@ __global__ __launch_bounds__(256) void resample_v4_kernel(const uint8_t* __restr
   const size_t tc = blockIdx.x / ((size_t)xblocks * ygroups);
   for (int idx = tid; idx < 4 * PV_R * vspan; idx += 256) pv_lds[idx] = 0;
   __syncthreads();
-  {   // thread -> (row of the workgroup, tap): scatter the row's taps to their offset in its wave's range
-    const int rr = tid >> 3, y = yg * 4 * PV_R + rr;          // 32 rows x 8 threads
+  {   // thread -> (row of the workgroup, tap): 16 threads per row scatter the row's taps to their offset in its wave's range
+    static_assert(256 / (4 * PV_R) == 16, "thread-to-row mapping of the tap scatter: 256 threads = 4 waves x PV_R rows x 16 threads");
+    const int rr = tid >> 4, y = yg * 4 * PV_R + rr;          // 4 * PV_R rows x 16 threads: every rr is a row this workgroup owns
     if (y < oh) {
       const int y0 = yg * 4 * PV_R + (rr / PV_R) * PV_R;
       const int base = bound[2 * y0], ymin = bound[2 * y], yn = bound[2 * y + 1];
-      for (int ti = tid & 7; ti < yn; ti += 8) {
+      for (int ti = tid & 15; ti < yn; ti += 16) {
         const int o = ymin - base + ti;
         if (o < vspan) pv_lds[rr * vspan + o] = coef[(size_t)y * ksize + ti];
       }

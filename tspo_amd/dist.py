@@ -53,24 +53,29 @@ def self_spawn(n: int, argv: Sequence[str], module: "str | None" = None, timeout
     non-zero exit code (the other ranks are terminated by PID as soon as one rank fails), else 0."""
     import subprocess
     import sys
+    import tempfile
     import time
     port = free_port()
     cmd = [sys.executable] + (["-m", module] if module else [argv[0]]) + list(argv[1:])
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSPO_SELF_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen(cmd, env=env))
-    t0, rc = time.monotonic(), 0
+        # stderr goes through a per-rank file so that a failing rank's last lines can be quoted in the launcher's own exit
+        # message (8 interleaved tracebacks on a terminal are unreadable); it is replayed to this process's stderr at the end
+        ef = tempfile.TemporaryFile(mode="w+b")
+        errs.append(ef)
+        procs.append(subprocess.Popen(cmd, env=env, stderr=ef))
+    t0, rc, failed = time.monotonic(), 0, None
     live = list(procs)
     while live and rc == 0:
         for p in list(live):
             code = p.poll()
             if code is not None:
                 live.remove(p)
-                if code != 0:
-                    rc = code
+                if code != 0 and rc == 0:
+                    rc, failed = code, procs.index(p)
         if timeout is not None and time.monotonic() - t0 > timeout:
             rc = 124
         if live and rc == 0:
@@ -82,6 +87,18 @@ def self_spawn(n: int, argv: Sequence[str], module: "str | None" = None, timeout
             p.wait(timeout=10)
         except subprocess.TimeoutExpired:
             p.kill()
+    tails = []
+    for r, ef in enumerate(errs):
+        ef.seek(0)
+        txt = ef.read().decode(errors="replace")
+        ef.close()
+        if txt:
+            sys.stderr.write(txt if n == 1 else "".join(f"[rank {r}] {ln}" for ln in txt.splitlines(True)))
+        tails.append(txt)
+    if rc != 0:
+        who = f"rank {failed}" if failed is not None else f"timeout after {timeout} s"
+        tail = "".join(tails[failed].splitlines(True)[-12:]) if failed is not None else ""
+        sys.stderr.write(f"self_spawn: {who} of {n} exited with code {rc}; the other ranks were stopped.  Last lines of its stderr:\n{tail}")
     return rc
 
 

@@ -68,11 +68,12 @@ class RolloutContext:
     """What `PolicyTrainer.rollout` saved for the matching backward: the selector workspace holding the activations
     of THAT forward, the shapes / temperature they belong to, and the parameter version they were computed with.
     Opaque to callers; `PolicyTrainer.backward` validates and consumes it (a context is good for one backward)."""
-    __slots__ = ("ws", "shape", "M", "tau", "param_version", "serial", "consumed", "owner")
+    __slots__ = ("ws", "shape", "M", "tau", "param_version", "serial", "consumed", "owner", "idx_ptr")
 
-    def __init__(self, ws, shape, M, tau, param_version, serial, owner):
+    def __init__(self, ws, shape, M, tau, param_version, serial, owner, idx_ptr=0):
         self.ws, self.shape, self.M, self.tau = ws, tuple(shape), M, float(tau)
         self.param_version, self.serial, self.consumed, self.owner = param_version, serial, False, owner
+        self.idx_ptr = idx_ptr              # the index tensor this rollout emitted (ascending by construction)
 
 
 class PolicyTrainer:
@@ -122,6 +123,7 @@ class PolicyTrainer:
         self._norm_ws = torch.empty((2048,), dtype=torch.uint8, device=flat.device)
         self._norm_part = torch.empty((2048,), dtype=torch.float32, device=flat.device)
         self._norm_np = 0                       # > 0: the last backward left the bucket's partial sums of squares there
+        self._norm_grad_version = -1            # ... for the bucket contents of THIS tensor version (an in-place edit invalidates them)
         self._rank = rank
 
     # ---- topology -----------------------------------------------------------------------------------------
@@ -161,7 +163,7 @@ class PolicyTrainer:
         scores, _, _ = ops.selector_forward(self.flat, feats, txt, clip, self.heads, self.window, tau, want_attn=False,
                                             ws=ws, precision=self.gemm_precision)
         out = ops.gumbel_topk(scores, k, G, noise=noise, seed=self._rank_seed(), offset=self._rollouts)
-        ctx = RolloutContext(ws, (B, T, D), txt.shape[1], tau, self._param_version, self._rollouts, self)
+        ctx = RolloutContext(ws, (B, T, D), txt.shape[1], tau, self._param_version, self._rollouts, self, out["idx"].data_ptr())
         self._rollouts += 1
         return scores, out["idx"], out["logp"], ctx
 
@@ -179,6 +181,11 @@ class PolicyTrainer:
                              f"this context belongs to ({ctx.shape}, M={ctx.M})")
         if self._micro >= self.grad_accum_steps:
             raise RuntimeError("gradient accumulation boundary reached: call optimizer_step() before another backward()")
+        if idx.data_ptr() != ctx.idx_ptr:
+            # an index tensor that is not the one this rollout emitted (e.g. a reference-style `ts_ids` in selection order): the
+            # gradient kernels find a frame's rollouts by binary search in ascending lists, so sort each rollout's list on
+            # the device (membership - all the policy gradient uses - does not depend on the order; no host sync)
+            idx = torch.sort(idx, dim=-1).values
         B = feats.shape[0]
         if self._micro == 0:
             target = self.grad
@@ -196,6 +203,7 @@ class PolicyTrainer:
             adv, loss, self._norm_np = ops.policy_backward(self.flat, target, feats, txt, rewards, logp, idx, self.heads,
                                                            self.window, ctx.tau, ctx.ws, scale=scale,
                                                            precision=self.gemm_precision, norm_partials=self._norm_part)
+            self._norm_grad_version = self.grad._version
         elif idx.shape[1] <= 64:    # advantage -> dL/dscores inside the backward's first kernel (one launch less)
             adv, loss = ops.policy_backward(self.flat, target, feats, txt, rewards, logp, idx, self.heads, self.window, ctx.tau,
                                             ctx.ws, scale=scale, precision=self.gemm_precision)
@@ -228,7 +236,10 @@ class PolicyTrainer:
         # mean at max_norm == clipping the sum at world*max_norm, then scaling by 1/world (no extra pass over the bucket)
         use_lr = lr if lr is not None else self.current_lr()
         self.step_no += 1
-        fused = self._norm_np > 0 and world == 1 and self.reduce_fn is self._reduce_default
+        # (the partial sums describe the bucket as the backward left it: `grad` is a public tensor, so an in-place edit between
+        # backward() and this call - a regulariser, a manual clip - falls back to the separate sum-of-squares pass)
+        fused = (self._norm_np > 0 and world == 1 and self.reduce_fn is self._reduce_default
+                 and self.grad._version == self._norm_grad_version)
         ns = ops.adamw_clip_step(self.flat, self.grad, self.m, self.v, self.n_train, use_lr, self.step_no, self.betas[0],
                                  self.betas[1], self.eps, self.wd, pre_scale=1.0 / world, max_norm=self.max_norm * world,
                                  out=self._norm_out, ws=self._norm_ws, norm_partials=self._norm_part if fused else None,

@@ -76,6 +76,31 @@ def extract_clip_features(clip_model, clip_processor, video, text):
     return extract_clip_features_impl(clip_model, clip_processor, video, text, 'llava')
 
 
+def meanstd(len_scores, dic_scores, n, fns, t1, t2, all_depth):
+    """The partition step of adaptive keyframe sampling under the reference's name and calling convention
+    (model/utils.py:83-126; `AKS_sampling` below does not go through it): segments `{"score": array, "depth": d}` with their
+    frame-number lists in, the final segments out - a segment whose best `n` scores stand out from its mean by more than `t1`
+    (and whose std exceeds `t2`) or that has been halved `all_depth` times is final, any other is halved.  Returned level by
+    level (final segments of depth d before those of depth d + 1, each level in input order), as the reference's recursion
+    concatenates them.  `len_scores` is unused there as well."""
+    done_s, done_f = [], []
+    level_s, level_f = list(dic_scores), list(fns)
+    while level_s:
+        next_s, next_f = [], []
+        for seg, frames in zip(level_s, level_f):
+            sc, depth = seg["score"], seg["depth"]
+            best = sorted(range(len(sc)), key=lambda i: -sc[i])[:n]          # stable: equal scores keep the lower frame first
+            if (np.mean([sc[i] for i in best]) - np.mean(sc) > t1 and np.std(sc) > t2) or depth >= all_depth:
+                done_s.append(seg)
+                done_f.append(frames)
+            else:
+                half = len(sc) // 2
+                next_s += [dict(score=sc[:half], depth=depth + 1), dict(score=sc[half:], depth=depth + 1)]
+                next_f += [frames[:half], frames[half:]]
+        level_s, level_f = next_s, next_f
+    return done_s, done_f
+
+
 def AKS_sampling(score, max_num_frames, t1: float = 0.2, t2: float = -100.0, all_depth: int = 3):
     """Adaptive keyframe sampling, the 'aks' branch of inference_ts (contract: model/utils.py:83-153 with its constants
     t1 = 0.2, t2 = -100, depth 3): a clip whose best `max_num_frames` frames stand out from its mean by more than t1 (on
