@@ -63,20 +63,31 @@ def test_product_has_no_cpu_fallback():
 
 
 def test_shipped_library_has_no_dev_hooks():
-    """The GEMM A/B variants / ablation kernels exist only in a -DTSPO_DEV_HOOKS build: the shipped library rejects
-    their variant numbers before touching the device and does not contain their kernels."""
-    from tspo_amd import _lib
+    """The product sources carry no conditional development code (round 4: the laboratory lives in csrc/dev/*.hip, linked in only
+    by `python -m tspo_amd.build --dev` and reached through a weak symbol): no TSPO_DEV_HOOKS / lab macro anywhere under csrc/
+    outside dev/, the shipped library rejects the lab variant numbers before touching the device, does not export the lab entry
+    points, holds none of the retired kernels and reads no environment variable."""
+    import glob
+    from tspo_amd import _lib, build as b
+    for f in glob.glob(os.path.join(b.CSRC, "*.hip")) + glob.glob(os.path.join(b.CSRC, "*.h")):
+        txt = open(f).read()
+        for marker in ("TSPO_DEV_HOOKS", "TSPO_A9_LAB", "TSPO_ATTN_NO_SGB", "getenv"):
+            assert marker not in txt, (f, marker)
+    assert all(s.startswith("dev/") for s in b.DEV_SOURCES) and not any(s.startswith("dev/") for s in b.SOURCES)
     l = _lib.lib()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    for variant in (2, 8, 9, 60, 69, 70, 71, 72, 76):   # 256x128 ring, compute-only / loads-only ablations, probe, role-split, 16-wave, DMA-kernel lab schedules
+    for variant in (2, 6, 8, 9, 60, 69, 70, 71, 72, 74, 75, 76, 78, 85):   # retired kernels / ablations / probes and the DMA-kernel lab schedules
         assert l.tspo_gemm_bf16(p, p, p, None, p, _lib.TSPO_BF16, 4096, 4096, 1024, variant << 8, None) == -1
-        assert b"not part of this build" in l.tspo_last_error()
+        assert b"not part of this build" in l.tspo_last_error(), (variant, l.tspo_last_error())
     blob = open(_lib.LIB_PATH, "rb").read()
-    for name in (b"gemm_bf16_p3_kernel", b"gemm_bf16_s256_kernel", b"gemm_bf16_w16_kernel", b"clip_attn257p_kernel",
-                 b"TSPO_GEMM_VARIANT", b"TSPO_ATTN_ABL", b"TSPO_SEL_SPLIT", b"getenv", b"tspo_dma_set_debug"):   # no env-driven behaviour either
+    for name in (b"gemm_bf16_p3_kernel", b"gemm_bf16_s256_kernel", b"gemm_bf16_w16_kernel", b"gemm_bf16_p256_kernel", b"clip_attn257p_kernel",
+                 b"clip_attn257w8_kernel", b"TSPO_GEMM_VARIANT", b"TSPO_ATTN_ABL", b"TSPO_SEL_SPLIT", b"getenv", b"tspo_dma_set_debug",
+                 b"tspo_lab_gemm_dma\0tspo_dev"):
         assert name not in blob, name
-    assert b"gemm_bf16_a9_kernel" in blob and b"gemm_bf16_a7_kernel" in blob and b"gemm_bf16_p256_kernel" in blob
+    for sym in ("tspo_dma_set_debug", "tspo_dev_set_debug"):
+        assert not hasattr(l, sym), sym
+    assert b"gemm_bf16_a9_kernel" in blob and b"gemm_bf16_a7_kernel" in blob
 
 
 @pytest.mark.parametrize("src,kernel", [("gemm_dma.hip", "gemm_bf16_a9_kernel"), ("gemm_agpr.hip", "gemm_bf16_a7_kernel")])

@@ -100,10 +100,10 @@ def test_pixels_to_indices_oracle_vs_hip(weights):
     print(f"    features: HIP {ferr:.4f} of range vs reference-bf16 {rf['err_over_range']:.4f}; 1-cos {1 - cosf:.2e} vs {1 - rf['min_cos']:.2e}")
     assert ferr <= 1.5 * rf["err_over_range"] and 1 - cosf <= 1.5 * (1 - rf["min_cos"])
     eps_by_text = {}
-    for tn, tx in texts.items():
+    for tn, tq in texts.items():
         with torch.no_grad():
-            sr, _ = O.selector_forward(selp, f_ref, tx, O.clip_cosine_scores(tx, f_ref), WINDOW, TAU)
-        i32, sh, _ = scorer(px, tx.to(DEV)[None], 32)
+            sr, _ = O.selector_forward(selp, f_ref, tq, O.clip_cosine_scores(tq, f_ref), WINDOW, TAU)
+        i32, sh, _ = scorer(px, tq.to(DEV)[None], 32)
         sh = sh[0].cpu()
         e = (sh - sr.float()).abs().max().item()
         eps_by_text[tn] = e

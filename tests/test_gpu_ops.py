@@ -543,7 +543,7 @@ def test_gemm_bf16_persistent_kernel_full_check(N, K):
         want, kw = ref + R.float(), dict(residual=R.to(DEV))
     else:
         want, kw = ref, {}
-    for variant in (0, 6, 82, 77):     # automatic choice, 8-wave LDS-DMA ring kernel, 4-wave AGPR kernels: register-staged / LDS-DMA operands
+    for variant in (0, 82, 77):     # automatic choice; the four-wave AGPR kernels: register-staged / LDS-DMA operands (0 = 77 for big shapes)
         act = kw.get("act", 0) | (variant << 8)
         out = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=act).float().cpu()
         np.testing.assert_allclose(out.numpy(), want.numpy(), err_msg=f"variant {variant}", **tol)

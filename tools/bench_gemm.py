@@ -5,7 +5,9 @@ Variants are timed interleaved (rotating order) over several rounds; the median 
 (torch.nn.functional.linear -> hipBLASLt) on the same operands, WITHOUT the activation / residual epilogue the
 hand-written kernels fuse (tool only; the product never calls it).
 
-    python tools/bench_gemm.py T variants rounds        e.g.  1024 6,80,-1 6
+    python tools/bench_gemm.py T variants rounds        e.g.  1024 82,77,-1 6
+Variants: 77 = production (LDS-DMA operands), 82 = register-staged four-wave kernel, -1 = vendor; 76 / 75 (schedule A/B, no-DMA
+ablation) need a `python -m tspo_amd.build --dev` library.
 Every variant's full output is also compared with the first variant's (bitwise where the K order is the same)."""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +15,7 @@ import torch
 from tspo_amd import ops
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [6, 80, -1]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [82, 77, -1]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 M = 257 * T
 dev = "cuda"

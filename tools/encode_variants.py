@@ -1,12 +1,19 @@
 #!/usr/bin/env python
-"""Whole-encode A/B of GEMM variants (--dev / --lab builds: TSPO_GEMM_VARIANT): repeatability and agreement with variant 82.
-    python tools/encode_variants.py [frames]"""
-import sys, os, subprocess
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-if len(sys.argv) > 2:
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import torch, bench
+"""Whole-encode check of library builds against each other (same convention as tools/ab_libs.sh: tmp_ab/lib_<name>.so): bitwise
+repeatability of each build and agreement with the first one, LayerNorm folded and stand-alone.
+    python tools/encode_variants.py frames name_a name_b ...        (run from the repository root on the GPU box)"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 2 and sys.argv[2] == "--child":
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
     from tspo_amd import ops
+    T, name, first = int(sys.argv[1]), sys.argv[3], sys.argv[4] == "1"
     DEV = torch.device("cuda", 0)
     c = bench.CLIP_L14
     clipw = ops.ClipVitWeights(bench.random_clip_state(c, DEV), c, DEV)
@@ -15,11 +22,13 @@ if len(sys.argv) > 2:
         f0 = ops.clip_vit_forward(clipw, px, fold_layernorm=fold).float()
         f1 = ops.clip_vit_forward(clipw, px, fold_layernorm=fold).float()
         ref_path = f"/tmp/enc_ref_{T}_{int(fold)}.pt"
-        if os.environ.get("TSPO_GEMM_VARIANT") == "82":
+        if first:
             torch.save(f0.cpu(), ref_path)
         ref = torch.load(ref_path).to(DEV)
-        print(f"variant {os.environ.get('TSPO_GEMM_VARIANT')} fold={fold}: repeat maxdiff {(f0 - f1).abs().max().item():.4g}; vs variant 82: "
+        print(f"{name} fold={fold}: repeat maxdiff {(f0 - f1).abs().max().item():.4g}; vs the first build: "
               f"{(f0 - ref).abs().max().item() / ref.abs().max().item():.4g} of range", flush=True)
 else:
-    for v in ("82", "77"):
-        subprocess.call([sys.executable, __file__, str(T), "child"], env=dict(os.environ, TSPO_GEMM_VARIANT=v))
+    T, names = sys.argv[1], sys.argv[2:]
+    for i, n in enumerate(names):
+        shutil.copy(os.path.join(ROOT, "tmp_ab", f"lib_{n}.so"), os.path.join(ROOT, "tspo_amd", "libtspo_hip.so"))
+        subprocess.call([sys.executable, __file__, T, "--child", n, "1" if i == 0 else "0"])

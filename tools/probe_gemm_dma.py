@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where a K-step of the LDS-DMA GEMM (a9) spends its cycles (--lab build; variant 74 = the production schedule):
+"""Where a K-step of the LDS-DMA GEMM (a9) spends its cycles (--dev build; variant 74 = the production schedule):
 s_memtime sums per wave: whole K-step, inside barrier 1 / 2, the vmcnt wait for the next stage, inside barrier 3.
     python tools/probe_gemm_dma.py """
 import sys, os

@@ -11,7 +11,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtspo_hip.so")
 SOURCES = ["sampler.hip", "selector.hip", "gemm_bf16.hip", "gemm_agpr.hip", "gemm_dma.hip", "clip_vit.hip", "preprocess.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_bf16.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_agpr_common.h"), os.path.join(os.path.dirname(PKG), "include", "tspo_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_bf16.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_agpr_common.h"),
+           os.path.join(CSRC, "gemm_dma_kernel.h"), os.path.join(os.path.dirname(PKG), "include", "tspo_hip.h")]
 
 
 def _hipcc() -> str:
@@ -29,15 +30,20 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, dev: bool = False, lab: bool = False, only=None) -> str:
-    """dev=True adds -DTSPO_DEV_HOOKS: the GEMM A/B variants, ablation branches and timing probes the tools/ scripts use
-    (some compute wrong results on purpose).  lab=True adds -DTSPO_A9_LAB: the schedule A/B variants of the LDS-DMA GEMM.
-    The shipped library is built WITHOUT either.  The translation units compile in parallel (one hipcc per source);
-    only=[...] recompiles just those sources and relinks with the other objects as they are."""
+DEV_SOURCES = ["dev/gemm_dma_lab.hip"]      # compiled into the library only by build(dev=True) / `--dev`
+
+
+def build(force: bool = False, verbose: bool = True, dev: bool = False, only=None) -> str:
+    """The translation units compile in parallel (one hipcc per source).  dev=True links the laboratory units of csrc/dev/
+    in as well (GEMM schedule A/Bs, a timing-only ablation, the K-step probe - what tools/probe_gemm_dma.py and the A/B
+    variants of tools/bench_gemm.py need); the product sources themselves carry no conditional code and the shipped library
+    is built WITHOUT them (tests/test_abi.py checks the binary).  only=[...] recompiles just those sources and relinks with
+    the other objects as they are."""
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
-    flags = (["-DTSPO_DEV_HOOKS"] if dev else []) + (["-DTSPO_A9_LAB"] if lab else []) + os.environ.get("TSPO_EXTRA_HIPCC_FLAGS", "").split()
+    flags = os.environ.get("TSPO_EXTRA_HIPCC_FLAGS", "").split()
+    sources = SOURCES + (DEV_SOURCES if dev else [])
 
     def compile_one(s):
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
@@ -51,8 +57,8 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, lab: boo
         return o
 
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -62,6 +68,5 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, lab: boo
 
 if __name__ == "__main__":
     only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
-    build(force=True if (only or "--force" in sys.argv or "--dev" in sys.argv or "--lab" in sys.argv) else False,
-          dev="--dev" in sys.argv, lab="--lab" in sys.argv, only=only[0] if only else None)
+    build(force=bool(only) or "--force" in sys.argv or "--dev" in sys.argv, dev="--dev" in sys.argv, only=only[0] if only else None)
     print(LIB)

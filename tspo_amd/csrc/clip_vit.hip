@@ -532,143 +532,7 @@ __device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const 
   for (int n = 0; n < NQ; ++n) lrun[n] = lsum[n][0];
 }
 
-#ifdef TSPO_DEV_HOOKS
-// Software-pipelined form of attn257_blocks<2, 6, true> over all three key blocks (the persistent kernel's main pass): the
-// score MFMAs of block b+1 are issued BEFORE the softmax of block b, so one wave's instruction stream always holds
-// independent matrix and vector work - the softmax (exp2 at quarter rate + max/fma/pack, ~1250 cycles per block and wave)
-// is longer than the 54 MFMAs of a block (~860 cycles) and, in a kernel whose waves all start an item together after a
-// barrier, nothing else would overlap the two pipes.
-__device__ __forceinline__ void attn257_pipe(const bf16x8 (&qf)[2][2], const char* Ks, const char* Vs, float scale, int l15,
-                                             int q4, float (&lrun)[2], f32x4 (&o)[2][4]) {
-  constexpr int NQ = 2, KT = 6, S = 257;
-  int voff[4][2];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int kr = hh * 16 + q4 * 4 + (l15 >> 2);
-      voff[dt][hh] = kr * 128 + (((dt * 2 + ((l15 & 3) >> 1)) ^ (kr & 7)) << 4) + (l15 & 1) * 8;
-    }
-  const int koff = l15 * 128, ksw = l15 & 7;
-  const float c2 = scale * 1.4426950408889634f;
-  float mrun[NQ];
-  f32x4 lsum[NQ];
-#pragma unroll
-  for (int n = 0; n < NQ; ++n) {
-    mrun[n] = -INFINITY;
-    lsum[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[n][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  union VF { bf16x8 v; s16x4 h2[2]; };
-  union { bf16x8 v; uint32_t u[4]; } ones;
-  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;   // bf16 1.0 x 8
-  auto qk = [&](const int b, f32x4 (&sc)[NQ][KT]) {
-    const char* kb = Ks + b * KT * 2048 + koff;
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      const bool live = b * KT + j <= 16;
-#pragma unroll
-      for (int n = 0; n < NQ; ++n) sc[n][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (live) {
-        const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kb + j * 2048 + ((q4 ^ ksw) << 4));
-        const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kb + j * 2048 + (((4 + q4) ^ ksw) << 4));
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-          sc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[n][0], sc[n][j], 0, 0, 0);
-          sc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[n][1], sc[n][j], 0, 0, 0);
-        }
-      }
-      if (b * KT + j >= 16) {   // key tile 16: only key 256 (row 0 of the tile) exists; tile 17: nothing
-#pragma unroll
-        for (int n = 0; n < NQ; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sc[n][j][r] = ((b * KT + j) * 16 + q4 * 4 + r) < S ? sc[n][j][r] : -INFINITY;
-      }
-    }
-  };
-  auto softmax_pv = [&](const int b, f32x4 (&sc)[NQ][KT]) {
-    float alpha[NQ];
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-      float mx = at_rowmax<KT>(sc[n]);
-      {
-        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = AT_MAX(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
-        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = AT_MAX(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
-      }
-      if (b == 0) {   // nothing accumulated yet: no rescale
-        mrun[n] = mx * c2;
-      } else {
-        const float mnew = AT_MAX(mrun[n], mx * c2);
-        alpha[n] = __builtin_amdgcn_exp2f(mrun[n] - mnew);
-        mrun[n] = mnew;
-        lsum[n] *= alpha[n];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[n][dt] *= alpha[n];
-      }
-    }
-    const char* vb = Vs + b * (KT / 2) * 4096;
-#pragma unroll
-    for (int c = 0; c < KT / 2; ++c) {
-      union { bf16x8 v; uint32_t u[4]; } pf[NQ];
-#pragma unroll
-      for (int n = 0; n < NQ; ++n) {
-        const f32x2 c2v = {c2, c2}, nm = {-mrun[n], -mrun[n]};
-        float e[8];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const f32x4 v = sc[n][2 * c + jj];
-          const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-          const f32x2 tl = lo * c2v + nm, th = hi * c2v + nm;   // v_pk_fma_f32
-          const int tile = b * KT + 2 * c + jj;
-          if (tile >= 17) {          // no such keys: P = 0
-            e[jj * 4 + 0] = e[jj * 4 + 1] = e[jj * 4 + 2] = e[jj * 4 + 3] = 0.f;
-          } else if (tile == 16) {   // key 256 alone (row 0 of the tile; the masked lanes hold -inf -> 0)
-            e[jj * 4 + 0] = __builtin_amdgcn_exp2f(tl[0]);
-            e[jj * 4 + 1] = e[jj * 4 + 2] = e[jj * 4 + 3] = 0.f;
-          } else {
-            e[jj * 4 + 0] = __builtin_amdgcn_exp2f(tl[0]); e[jj * 4 + 1] = __builtin_amdgcn_exp2f(tl[1]);
-            e[jj * 4 + 2] = __builtin_amdgcn_exp2f(th[0]); e[jj * 4 + 3] = __builtin_amdgcn_exp2f(th[1]);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pf[n].u[i] = pack_bf16x2(e[2 * i], e[2 * i + 1]);
-        lsum[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pf[n].v, lsum[n], 0, 0, 0);   // row sums of the bf16 P
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        VF f;
-        f.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + voff[dt][0] + c * 4096));
-        f.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + voff[dt][1] + c * 4096));
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) o[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, pf[n].v, o[n][dt], 0, 0, 0);
-      }
-    }
-  };
-  f32x4 sa[NQ][KT], sb[NQ][KT];
-  qk(0, sa);
-  qk(1, sb);
-  softmax_pv(0, sa);
-  qk(2, sa);
-  softmax_pv(1, sb);
-  softmax_pv(2, sa);
-#ifndef TSPO_ATTN_NO_SGB
-  // scheduling pattern for the block above: one MFMA, then a handful of vector instructions, repeated
-#pragma unroll
-  for (int i = 0; i < 176; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // VALU
-  }
-#endif
-#pragma unroll
-  for (int n = 0; n < NQ; ++n) lrun[n] = lsum[n][0];
-}
-#endif  // TSPO_DEV_HOOKS
 
-// ABL (dev builds only): 1 = staging + stores without the attention math, 2 = the math without the global loads
-template <int ABL>
 __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int C,
                                                               float scale) {
   constexpr int S = 257;
@@ -695,11 +559,6 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
       const int id = tid + i * 256;
       const int row = id >> 3, c = id & 7;
       const int rc = row < S ? row : S - 1;
-      if (ABL == 2) {
-        kv[i] = uint4{0x3c003c00u + id, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-        vv[i] = kv[i];
-        continue;
-      }
       kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + C + c * 8);
       vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + 2 * C + c * 8);
     }
@@ -719,19 +578,6 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
   {   // this wave's 64 queries
     float m4[4], l4[4];
     f32x4 o4[4][4];
-    if (ABL == 1) {
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        l4[n] = 1.f;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const uint4 t = *reinterpret_cast<const uint4*>(Ks + (n * 4 + dt) * 1024 + tid * 16);
-          union { bf16x8 v; uint32_t u[4]; } qq;
-          qq.v = qf4[n][dt & 1];
-          o4[n][dt] = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w ^ qq.u[0])};
-        }
-      }
-    } else
     attn257_blocks<4>(qf4, Ks, Vt, scale, 0, 3, l15, q4, m4, l4, o4);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -748,7 +594,6 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
     }
   }
   // token 256 (query tile 16, row 0): waves 0..2 take one key block each
-  if (ABL == 1) return;
   if (wid < 3) {
     float m1[1], l1[1];
     f32x4 o1[1][4];
@@ -777,273 +622,11 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
   }
 }
 
-#ifdef TSPO_DEV_HOOKS
-// Round-3 A/B (dev builds, TSPO_ATTN_W8=1; measured 17.3 ms per forward against 13.0 ms for the shipped kernel on the same
-// box - twice the fragment reads per MFMA and 24 spilled registers cost more than the extra waves hide): the same item with EIGHT waves of TWO query tiles each (32 queries per wave) and at most 128 registers, so
-// that two workgroups = four waves share a SIMD instead of two: the softmax is a chain of dependent vector instructions
-// (quarter-rate exp2 on MFMA results) and two waves per SIMD leave its latencies exposed (MFMA busy 31 %, 42 % of wave
-// cycles waiting for issue).  Costs twice the K / V^T fragment reads per MFMA (each read feeds 2 instead of 4).
-__global__ __launch_bounds__(512, 4) void clip_attn257w8_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int C,
-                                                                float scale) {
-  constexpr int S = 257;
-  __shared__ __attribute__((aligned(16))) char lds[A4_LDS_BYTES];
-  char* Ks = lds;
-  char* Vt = lds + AT_KEYS * 128;
-  float* part = reinterpret_cast<float*>(lds + A4_PART_OFF);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l15 = lane & 15, q4 = lane >> 4;
-  const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
-  const int item = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
-  const int h = item % (int)gridDim.x;
-  const size_t f = item / (int)gridDim.x;
-  const size_t ld = (size_t)3 * C;
-  const bf16_t* base = qkv + f * S * ld + (size_t)h * 64;
-  bf16x8 qf2[2][2];
-  {
-    uint4 kv[5], vv[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int id = tid + i * 512;
-      const int row = id >> 3, c = id & 7;
-      const int rc = row < S ? row : S - 1;
-      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + C + c * 8);
-      vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + 2 * C + c * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int id = tid + i * 512;
-      const int row = id >> 3, c = id & 7;
-      if (row < AT_KEYS) {
-        const uint4 z = {0u, 0u, 0u, 0u};
-        const uint4 k4 = row < S ? kv[i] : z, v4 = row < S ? vv[i] : z;
-        *reinterpret_cast<uint4*>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = k4;
-        *reinterpret_cast<uint4*>(Vt + ((row >> 5) * 4 + (c >> 1)) * A4_VSUB + (row & 31) * 32 + (c & 1) * 16) = v4;
-      }
-      if (i == 0) attn257_load_q<2>(base, ld, wid * 2, l15, q4, qf2);
-    }
-  }
-  __syncthreads();
-  {
-    float m2[2], l2[2];
-    f32x4 o2[2][4];
-    attn257_blocks<2>(qf2, Ks, Vt, scale, 0, 3, l15, q4, m2, l2, o2);
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int qrow = (wid * 2 + n) * 16 + l15;
-      const float inv = 1.f / l2[n];
-      bf16_t* orow = out + (f * S + qrow) * (size_t)C + (size_t)h * 64;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        uint2 pk;
-        pk.x = pack_bf16x2(o2[n][dt][0] * inv, o2[n][dt][1] * inv);
-        pk.y = pack_bf16x2(o2[n][dt][2] * inv, o2[n][dt][3] * inv);
-        *reinterpret_cast<uint2*>(orow + dt * 16 + q4 * 4) = pk;
-      }
-    }
-  }
-  if (wid < 3) {
-    float m1[1], l1[1];
-    f32x4 o1[1][4];
-    bf16x8 qf1[1][2];
-    attn257_load_q<1>(base, ld, 16, l15, q4, qf1);
-    attn257_blocks<1>(qf1, Ks, Vt, scale, wid, wid + 1, l15, q4, m1, l1, o1);
-    if (l15 == 0) {
-      float* pw = part + wid * 68;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pw[dt * 16 + q4 * 4 + r] = o1[0][dt][r];
-      if (q4 == 0) { pw[64] = m1[0]; pw[65] = l1[0]; }
-    }
-  }
-  __syncthreads();
-  if (tid < 64) {
-    const float ma = part[64], mb = part[68 + 64], mc = part[136 + 64];
-    const float m = fmaxf(ma, fmaxf(mb, mc));
-    const float wa = __builtin_amdgcn_exp2f(ma - m), wb = __builtin_amdgcn_exp2f(mb - m), wc = __builtin_amdgcn_exp2f(mc - m);
-    const float l = part[65] * wa + part[68 + 65] * wb + part[136 + 65] * wc;
-    const float ov = (part[tid] * wa + part[68 + tid] * wb + part[136 + tid] * wc) / l;
-    const float on = __shfl_down(ov, 1, 64);
-    if ((tid & 1) == 0)
-      *reinterpret_cast<uint32_t*>(out + (f * S + 256) * (size_t)C + (size_t)h * 64 + tid) = pack_bf16x2(ov, on);
-  }
-}
-#endif  // TSPO_DEV_HOOKS (clip_attn257w8_kernel)
 
-// ===========================================================================
-// (dev builds only - measured, not shipped: see the end of this comment)
-// Persistent form of the kernel above: one 8-wave workgroup per CU walks over (frame, head) items.  K and V of item i+1
-// travel global -> LDS by LDS-DMA (no registers, no waiting wave) into the second of two 72 KB buffers while item i is
-// being computed, so the staging phase - 60 % of the time of the one-item-per-workgroup kernel when run alone
-// (profiles/r2_d_attn_ablation.json) - leaves the critical path.  Both operands use the same LDS image: [288 keys][128 B]
-// rows, 16-byte chunks XOR-swizzled by key & 7, written as 8-row pieces (33 per operand; piece 32 holds only key 256 and
-// is issued for 8 lanes).  Rows 257..287 are zeroed once and never written again.  A wave owns TWO query tiles (16 tiles
-// over 8 waves) for all three key blocks; the 257th query (token 256) is split over the waves by 32-key chunk, its
-// (max, sum, O row) partials are merged by wave 0 after the next barrier.  One barrier per item.
-// Item order: the 32 workgroups of an XCD (blockIdx % 8, speed only) take 32 consecutive items = the 16 heads of two
-// frames, i.e. whole 6 KB rows of qkv are consumed through one L2 at about the same time.
-// Outcome (profiles/r2_e_attn_persistent_ab.json): with the staging off the critical path the kernel takes the same
-// 15.0-15.9 ms on every box, where the one-item kernel takes 14.0 (boxes with fast memory) to 17.1 ms; its math phase
-// is slower than the one-item kernel's (two query tiles per wave = twice the LDS fragment traffic per MFMA, all eight
-// waves in lockstep after the per-item barrier, so the matrix and vector pipes alternate instead of overlapping).
-#ifdef TSPO_DEV_HOOKS
-#define AP_OPER (AT_KEYS * 128)                 // one operand image
-#define AP_BUF (2 * AP_OPER)                    // K | V
-#define AP_PART_OFF (2 * AP_BUF)                // partials of the token-256 row: [2 parities][9 chunks][68] floats
-#define AP_LDS_BYTES (AP_PART_OFF + 2 * 9 * 68 * 4)
-
-// The DMA instructions are issued from inline asm on purpose: hipcc, seeing an LDS-DMA in flight, puts s_waitcnt vmcnt(0)
-// in front of the first ds_read_b64_tr_b16 of the compute phase (it cannot prove that the read does not alias the DMA
-// target) - which would wait for the NEXT item's operands in the middle of the current one.  The kernel's own
-// s_waitcnt vmcnt(0) + barrier at the top of every item is the only synchronisation these transfers need.
-__device__ __forceinline__ void attn257p_dma16(const bf16_t* src, const char* dst_uniform) {
-  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)dst_uniform);
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
-}
-
-__device__ __forceinline__ void attn257p_stage(const bf16_t* __restrict__ base, size_t ld, int C, char* buf, int wid, int lane) {
-  const int rin = lane >> 3, slot = lane & 7;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {   // pieces wid, wid + 8, wid + 16, wid + 24 of K and of V
-    const int piece = wid + 8 * i;
-    const bf16_t* src = base + (size_t)(piece * 8 + rin) * ld + ((slot ^ rin) << 3);
-    attn257p_dma16(src + C, buf + piece * 1024);
-    attn257p_dma16(src + 2 * C, buf + AP_OPER + piece * 1024);
-  }
-  if (wid < 2 && rin == 0)        // piece 32 = key 256 alone: wave 0 brings K's, wave 1 V's (8 lanes)
-    attn257p_dma16(base + (size_t)256 * ld + (slot << 3) + (wid + 1) * C, buf + wid * AP_OPER + 32 * 1024);
-}
-
-template <int ABL>   // (dev builds only) 1: staging + barrier without the math; 2: the math without the staging
-__global__ __launch_bounds__(512, 1) void clip_attn257p_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int C,
-                                                               int H, int nitems, float scale) {
-  constexpr int S = 257;
-  __shared__ __attribute__((aligned(16))) char lds[AP_LDS_BYTES];   // 149.6 KB: one workgroup per CU
-  float* part = reinterpret_cast<float*>(lds + AP_PART_OFF);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l15 = lane & 15, q4 = lane >> 4;
-  const size_t ld = (size_t)3 * C;
-  const int G = gridDim.x, w = blockIdx.x;
-  const int niter = (nitems + G - 1) / G;
-  auto item_of = [&](int t) { return (G & 7) == 0 ? (t * 8 + (w & 7)) * (G >> 3) + (w >> 3) : t * G + w; };
-  auto base_of = [&](int item) { return qkv + (size_t)(item / H) * S * ld + (size_t)(item % H) * 64; };
-  // rows 257..287 of all four operand images are zero for the whole kernel
-  for (int i = tid; i < 4 * 31 * 8; i += 512) {
-    const int img = i / (31 * 8), r = i % (31 * 8);
-    *reinterpret_cast<uint4*>(lds + img * AP_OPER + 257 * 128 + r * 16) = uint4{0u, 0u, 0u, 0u};
-  }
-  bf16x8 qn[2][2], qt[1][2];   // Q fragments of the NEXT item (this wave's two query tiles, and the token-256 tile)
-  int item = item_of(0);
-  if (item < nitems) {
-    const bf16_t* b0 = base_of(item);
-    if (ABL != 2) attn257p_stage(b0, ld, C, lds, wid, lane);
-    attn257_load_q<2>(b0, ld, wid * 2, l15, q4, qn);
-    attn257_load_q<1>(b0, ld, 16, l15, q4, qt);
-  }
-  int prev_item = -1;
-  for (int t = 0; t < niter; ++t) {
-    item = item_of(t);
-    const bool have = item < nitems;   // workgroup-uniform
-    char* cur = lds + (t & 1) * AP_BUF;
-    // item t has landed (every wave waits for its own pieces, the barrier publishes them); every wave is past its reads of
-    // the other buffer (item t-1) and past its partial writes
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) - as a builtin, so that hipcc's own wait bookkeeping restarts from zero here
-    __syncthreads();
-    bf16x8 qf[2][2], qf1[1][2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) qf[n][kk] = qn[n][kk];
-    qf1[0][0] = qt[0][0];
-    qf1[0][1] = qt[0][1];
-    const int nxt = item_of(t + 1);
-    if (t + 1 < niter && nxt < nitems) {
-      const bf16_t* bn = base_of(nxt);
-      if (ABL != 2) attn257p_stage(bn, ld, C, lds + ((t + 1) & 1) * AP_BUF, wid, lane);
-      attn257_load_q<2>(bn, ld, wid * 2, l15, q4, qn);
-      attn257_load_q<1>(bn, ld, 16, l15, q4, qt);
-    }
-    if (prev_item >= 0 && tid < 64) {   // wave 0: merge the nine partials of the previous item's token-256 row
-      const float* pp = part + ((t - 1) & 1) * 9 * 68;
-      float m = pp[64];
-#pragma unroll
-      for (int c = 1; c < 9; ++c) m = fmaxf(m, pp[c * 68 + 64]);
-      float l = 0.f, ov = 0.f;
-#pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        const float wc = __builtin_amdgcn_exp2f(pp[c * 68 + 64] - m);
-        l += pp[c * 68 + 65] * wc;
-        ov += pp[c * 68 + tid] * wc;
-      }
-      ov /= l;
-      const float on = __shfl_down(ov, 1, 64);
-      if ((tid & 1) == 0)
-        *reinterpret_cast<uint32_t*>(out + ((size_t)(prev_item / H) * S + 256) * (size_t)C + (size_t)(prev_item % H) * 64 + tid) =
-            pack_bf16x2(ov, on);
-    }
-    prev_item = have ? item : -1;
-    if (!have) continue;
-    if (ABL == 1) {
-      if (tid == 0) out[(size_t)item * 64] = qf[0][0][0] + qf1[0][0][0];
-      prev_item = -1;
-      continue;
-    }
-    const size_t f = item / H;
-    const int h = item % H;
-    {   // this wave's 32 queries
-      float l2[2];
-      f32x4 o2[2][4];
-      attn257_pipe(qf, cur, cur + AP_OPER, scale, l15, q4, l2, o2);
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int qrow = (wid * 2 + n) * 16 + l15;
-        const float inv = 1.f / l2[n];
-        bf16_t* orow = out + (f * S + qrow) * (size_t)C + (size_t)h * 64;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          uint2 pk;
-          pk.x = pack_bf16x2(o2[n][dt][0] * inv, o2[n][dt][1] * inv);
-          pk.y = pack_bf16x2(o2[n][dt][2] * inv, o2[n][dt][3] * inv);
-          *reinterpret_cast<uint2*>(orow + dt * 16 + q4 * 4) = pk;
-        }
-      }
-    }
-    // token 256: 32-key chunk `wid` (wave 7 also takes chunk 8 = key 256 itself)
-    for (int c = wid; c < 9; c += 8) {
-      float m1[1], l1[1];
-      f32x4 o1[1][4];
-      attn257_blocks<1, 2, true>(qf1, cur, cur + AP_OPER, scale, c, c + 1, l15, q4, m1, l1, o1);
-      if (l15 == 0) {
-        float* pw = part + (t & 1) * 9 * 68 + c * 68;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pw[dt * 16 + q4 * 4 + r] = o1[0][dt][r];
-        if (q4 == 0) { pw[64] = m1[0]; pw[65] = l1[0]; }
-      }
-    }
-  }
-  __syncthreads();
-  if (prev_item >= 0 && tid < 64) {
-    const float* pp = part + ((niter - 1) & 1) * 9 * 68;
-    float m = pp[64];
-#pragma unroll
-    for (int c = 1; c < 9; ++c) m = fmaxf(m, pp[c * 68 + 64]);
-    float l = 0.f, ov = 0.f;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      const float wc = __builtin_amdgcn_exp2f(pp[c * 68 + 64] - m);
-      l += pp[c * 68 + 65] * wc;
-      ov += pp[c * 68 + tid] * wc;
-    }
-    ov /= l;
-    const float on = __shfl_down(ov, 1, 64);
-    if ((tid & 1) == 0)
-      *reinterpret_cast<uint32_t*>(out + ((size_t)(prev_item / H) * S + 256) * (size_t)C + (size_t)(prev_item % H) * 64 + tid) =
-          pack_bf16x2(ov, on);
-  }
-}
-#endif  // TSPO_DEV_HOOKS
+// Measured and gone from the tree (results: profiles/r2_d_attn_ablation.json, r2_e_attn_persistent_ab.json; code: git
+// history up to 99eb127): a persistent 8-wave form with LDS-DMA double-buffered staging (15.0-15.9 ms per forward on every box
+// against 12.6-14.0 for the kernel above: its two-tiles-per-wave math phase is slower), an 8-wave / 2-tile form at <= 128
+// registers (17.3 ms), a two-pass softmax (30.9 ms), staging-only / math-only ablation builds.
 
 // ===========================================================================
 struct ClipWs {
@@ -1373,21 +956,10 @@ extern "C" int tspo_gemm_bf16(const void* A, const void* W, const float* bias, c
   } else {
     TSPO_REQUIRE(out_dtype == TSPO_BF16, "gemm_bf16: out_dtype must be TSPO_BF16 or TSPO_F32");
     TSPO_REQUIRE(bias, "gemm_bf16: bf16 output needs a bias vector");
-#ifdef TSPO_DEV_HOOKS
-    TSPO_REQUIRE(!(residual && act) || variant == 69, "gemm_bf16: residual and activation are exclusive");
-#else
     TSPO_REQUIRE(!(residual && act), "gemm_bf16: residual and activation are exclusive");
-#endif
     epi = residual ? GE_RESID : (act == 1 ? GE_GELU : GE_BIAS);
   }
   g.variant = variant;
-#ifdef TSPO_DEV_HOOKS
-  if (variant == 69) {   // timing probe: the `residual` argument is a float debug buffer [256*8*4], not a residual
-    g.pos = reinterpret_cast<const float*>(residual);
-    g.R = nullptr;
-    epi = act == 1 ? GE_GELU : GE_BIAS;
-  }
-#endif
   return tspo::gemm_bf16(epi, g, (hipStream_t)stream);
 }
 
@@ -1504,22 +1076,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       pooled_done = true;
       break;
     }
-#ifdef TSPO_DEV_HOOKS
-    static const int attn_abl = getenv("TSPO_ATTN_ABL") ? atoi(getenv("TSPO_ATTN_ABL")) : 0;
-    static const int attnp_abl = getenv("TSPO_ATTNP_ABL") ? atoi(getenv("TSPO_ATTNP_ABL")) : 0;
-    if (S == 257 && attn_abl == 1) hipLaunchKernelGGL(clip_attn257_kernel<1>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
-    else if (S == 257 && attn_abl == 2) hipLaunchKernelGGL(clip_attn257_kernel<2>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
-    else if (S == 257 && attnp_abl == 1)
-      hipLaunchKernelGGL(clip_attn257p_kernel<1>, dim3(256), dim3(512), 0, st, b.qkv, b.a, C, c.heads, c.heads * n_frames, 0.125f);
-    else if (S == 257 && attnp_abl == 2)
-      hipLaunchKernelGGL(clip_attn257p_kernel<2>, dim3(256), dim3(512), 0, st, b.qkv, b.a, C, c.heads, c.heads * n_frames, 0.125f);
-    else if (S == 257 && getenv("TSPO_ATTN_W8") && getenv("TSPO_ATTN_W8")[0])
-      hipLaunchKernelGGL(clip_attn257w8_kernel, dim3(c.heads, n_frames), dim3(512), 0, st, b.qkv, b.a, C, 0.125f);
-    else if (S == 257 && (long)c.heads * n_frames >= 512 && getenv("TSPO_ATTN_PERSISTENT"))
-      hipLaunchKernelGGL(clip_attn257p_kernel<0>, dim3(256), dim3(512), 0, st, b.qkv, b.a, C, c.heads, c.heads * n_frames, 0.125f);
-    else
-#endif
-    if (S == 257) hipLaunchKernelGGL(clip_attn257_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
+    if (S == 257) hipLaunchKernelGGL(clip_attn257_kernel, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
     else hipLaunchKernelGGL(clip_attn_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     if (int e = tspo::check_launch("clip_attn")) return e;
     prof.tick(PK_ATTN);

@@ -25,12 +25,9 @@
 
 namespace {
 
-// A2: A staged two K-steps ahead in two register sets (else one set, one K-step ahead).  PRE0: slice 0's small epilogue
-// inputs are requested behind the tile's last K-step (else at the start of the epilogue).  Both cost VGPRs.
-// RW ("relaxed waits"): no lgkmcnt(0) drain between a K-step's [B] half and the next K-step's [A] half - there is no
-// barrier there, so only the register dependencies of the first MFMAs have to be met and the last ds_write / W-fragment
-// read of [B] may still be in flight when [A] starts.  DEV: development probes (0 in the shipped library).
-template <int EPI, bool A2, bool PRE0, bool RW = false, int DEV = 0>
+// (The A/B forms of round 2-3 - A staged two K-steps ahead, relaxed waits, deferred stores, staggered starts, the s_memtime
+// probes - were measured and are gone from the tree: profiles/r2_g_*, r3_a_gemm_path_probes.txt; code: git history up to 99eb127.)
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int tilesM, int ngrp) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE];  // the ONLY LDS object
   const int tid = threadIdx.x, lane = tid & 63;
@@ -44,23 +41,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
   const int ntile_x = panels * n_per;
   const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
   if (my_tiles == 0) return;
-#ifdef TSPO_DEV_HOOKS
-  if (DEV & 6) {   // A/B: workgroups of an XCD start out of phase (wl x 0.2 us / 0.4 us), spreading the XCD's store bursts
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)wl * ((DEV & 2) ? 20 : 40);
-    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
   A4_FENCE();   // claims a[0:255] for this kernel
 
-  // ---- staging registers: this wave's 8 W pieces of a stage (one set, loaded ONE K-step ahead: W is re-read by every
-  //      tile and lives in L2) and its 8 A pieces in TWO sets, loaded TWO K-steps ahead: every K-step's A slice is a
-  //      first touch of HBM data whose latency under load exceeds a K-step - with one set the ds_write of every K-step
-  //      waited for it (and loads return in order, so everything behind it waited too) ----
+  // ---- staging registers: this wave's 8 W pieces and 8 A pieces of a stage, each loaded one K-step before its ds_write
+  //      (a second A set, two K-steps ahead, was measured in round 2: no gain, 32 more VGPRs) ----
   const int rin = lane >> 3, slot = lane & 7;
   const unsigned lane_goff = ((unsigned)rin * (unsigned)g.K + (unsigned)(slot << 3)) * 2u;   // plain 128-byte rows
   const int lane_woff = rin * 128 + ((slot ^ rin) << 4);                                      // swizzled LDS image
   const unsigned piece_stride = 8u * (unsigned)g.K * 2u;
-  u32x4 sa0[8], sa1[8], sw_[8];
+  u32x4 sa0[8], sw_[8];
   // the stage the A registers / the W registers are loaded for NEXT: K-step inside the tile, tile, resource descriptor
   // (rows past the matrix end - and whole tiles past the last one - fall outside num_records and read as zeros)
   int a_kt = 0, a_s = wl, w_kt = 0, w_s = wl;
@@ -79,17 +68,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
   __amdgpu_buffer_rsrc_t a_rs = rsrc_a(a_s), w_rs = rsrc_w(w_s);
   auto adv_a = [&]() { if (++a_kt == nk) { a_kt = 0; a_s += nwl; a_rs = rsrc_a(a_s); } };
   auto adv_w = [&]() { if (++w_kt == nk) { w_kt = 0; w_s += nwl; w_rs = rsrc_w(w_s); } };
-  // DEV bits 3 / 4 (timing experiments only, wrong results): the W / A operand addressed as if stored in 8-row x 64-column
-  // blocks of 1 KB (a staging piece = ONE contiguous KB instead of 8 rows of 128 B at a pitch of 2*K bytes)
-  const unsigned lane_boff = (unsigned)lane * 16u;
   auto gload_a = [&](auto q_, u32x4 (&sa)[8]) {
     constexpr int q = decltype(q_)::value;
-    sa[q] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (DEV & 16) ? lane_boff + (unsigned)a_kt * 1024u : lane_goff + (unsigned)a_kt * (GT_BK * 2u),
+    sa[q] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, lane_goff + (unsigned)a_kt * (GT_BK * 2u),
                                                   (unsigned)(wid * 8 + q) * piece_stride, 0);
   };
   auto gload_w = [&](auto q_) {
     constexpr int q = decltype(q_)::value;
-    sw_[q] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, (DEV & 8) ? lane_boff + (unsigned)w_kt * 1024u : lane_goff + (unsigned)w_kt * (GT_BK * 2u),
+    sw_[q] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane_goff + (unsigned)w_kt * (GT_BK * 2u),
                                                    (unsigned)(wid * 8 + q) * piece_stride, 0);
   };
   auto swrite_a = [&](auto q_, const u32x4 (&sa)[8], int buf) {
@@ -101,8 +87,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     *reinterpret_cast<u32x4*>(lds + buf * G3_STAGE + G3_BM * 128 + (wid * 8 + q) * 1024 + lane_woff) = sw_[q];
   };
 
-  // ---- prologue: stage 0 complete in buffer 0; A of stage 1 in buffer 1, W of stage 1 in the W registers; A of stages
-  //      2 and 3 in A register sets 0 and 1 ----
+  // ---- prologue: stage 0 complete in buffer 0; A of stage 1 in buffer 1, W of stage 1 in the W registers; A of stage 2
+  //      in the A registers ----
   sfor<0, 8>([&](auto q_) { gload_a(q_, sa0); gload_w(q_); });
   sfor<0, 8>([&](auto q_) { swrite_a(q_, sa0, 0); swrite_w(q_, 0); });
   adv_a(); adv_w();
@@ -111,10 +97,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
   adv_a(); adv_w();   // w cursor -> stage 2 (loaded in [A] of K-step 0, after stage 1's W went to LDS)
   sfor<0, 8>([&](auto q_) { gload_a(q_, sa0); });
   adv_a();
-  if (A2) {
-    sfor<0, 8>([&](auto q_) { gload_a(q_, sa1); });
-    adv_a();
-  }
 
   // ---- fragments: A double-buffered per K-half (2 x 32 VGPRs); W in ONE set of 8 x 4 VGPRs refilled in place: the
   //      fragment of column tile nn is dead after its 8 MFMAs, so the next K-half's fragment nn is read right behind them ----
@@ -168,27 +150,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     });
   };
 
-  unsigned long long bar_cycles = 0, ks_cycles = 0, ks_last = 0, ks_count = 0;
   int it = 0, c_s = wl;
-  // DEV bit 5 (timing experiment, wrong results): "deferred stores" - the epilogue leaves slice 1 of the tile unstored and the
-  // next tile's first two K-steps issue those 16 stores per wave (dummy data: the W staging registers) behind their MFMAs
-  int dcount = 16, pm0 = 0, pn0 = 0;
-  auto defer_store = [&](auto j_) {
-    constexpr int j = decltype(j_)::value;
-    if ((DEV & 64) && dcount < 16) {      // thin form: ONE store per K-step (behind column tile 4), 16 K-steps to drain
-      if (j == 4) {
-        const int sidx = dcount, mi = sidx >> 1, pr = sidx & 1;
-        const int m = pm0 + wm * 128 + mi * 16 + l15;
-        const int n = pn0 + (wn * 2 + 1) * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
-        if (m < g.M && n < g.N) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + (size_t)m * g.N + n) = sw_[0];
-      }
-    } else if ((DEV & 32) && dcount < 16) {
-      const int sidx = dcount + j, mi = sidx >> 1, pr = sidx & 1;
-      const int m = pm0 + wm * 128 + mi * 16 + l15;
-      const int n = pn0 + (wn * 2 + 1) * 64 + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
-      if (m < g.M && n < g.N) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + (size_t)m * g.N + n) = sw_[j];
-    }
-  };
   auto kstep = [&](auto zero_, u32x4 (&sa)[8]) {
     const int cb = it & 1, nb = cb ^ 1;
     const char* cur = lds + cb * G3_STAGE;
@@ -198,68 +160,25 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
       if (decltype(ph_)::value == 0) swrite_w(j_, nb); else gload_w(j_);
     });
     adv_w();
-#ifdef TSPO_DEV_HOOKS
-    if (DEV & 128) {   // probe: cycles this wave spends in the per-K-step wait + barrier, and in a whole K-step
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bar_cycles += tb1 - tb0;
-      if (ks_last) ks_cycles += tb0 - ks_last;
-      ks_last = tb0;
-      ++ks_count;
-    } else
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage it+1 complete in LDS; buffer cb fully read
     __builtin_amdgcn_s_waitcnt(0xC07F);   // (the same wait as a builtin: free at run time, keeps hipcc's wait model exact)
     // [B]: K-half 1; fragments of K-half 0 of stage it+1; A pieces of set `sa`: S_j(it+2) -> buffer cb, then G_j(it+4)
     khalf(std::false_type{}, std::integral_constant<int, 1>{}, fa1, fa0, nxt, 0, [&](auto j_, auto ph_) {
-      if (decltype(ph_)::value == 0) swrite_a(j_, sa, cb); else { gload_a(j_, sa); defer_store(j_); }
+      if (decltype(ph_)::value == 0) swrite_a(j_, sa, cb); else gload_a(j_, sa);
     });
-    if ((DEV & 64) && dcount < 16) dcount += 1;
-    else if ((DEV & 32) && dcount < 16) dcount += 8;
     adv_a();
-    if (!RW) __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
     ++it;
   };
-#ifdef TSPO_DEV_HOOKS
-  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos));
-  auto probe = [&](int t, int i) {
-    if ((DEV & 1) && t < 24) {
-      const unsigned long long c = __builtin_amdgcn_s_memtime();
-      if (tid == 0) dbg[((size_t)blockIdx.x * 24 + t) * 6 + i] = c;
-      if (i == 0) { const unsigned long long r = __builtin_amdgcn_s_memrealtime(); if (tid == 0) dbg[((size_t)blockIdx.x * 24 + t) * 6 + 5] = r; }
-    }
-  };
-#else
-  auto probe = [&](int, int) {};
-#endif
-  for (int t = 0; t < my_tiles; ++t) {   // nk even: K-step kt of a tile always uses A register set kt & 1
+  for (int t = 0; t < my_tiles; ++t) {
     int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
-    probe(t, 0);
     kstep(std::true_type{}, sa0);                              // first K-step: its K-half 0 starts the accumulators (C = 0)
-    for (int kt = 1; kt < nk - 1; kt += 2) {
-      kstep(std::false_type{}, A2 ? sa1 : sa0);
-      kstep(std::false_type{}, sa0);
-    }
+    for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, sa0);
     EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
-    if (PRE0) epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
-    kstep(std::false_type{}, A2 ? sa1 : sa0);
-    if (!PRE0) epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
-    probe(t, 1);
-#ifdef TSPO_DEV_HOOKS
-    if (A7_ABL(g, 2)) { m0 = blockIdx.x * G3_BM; n0 = 0; }     // every tile of this workgroup stores to (and reads its residual from) ONE hot tile
-    if (A7_ABL(g, 1)) {                                        // epilogue arithmetic only: no stores, no residual loads
-      GemmArgs h = g;
-      h.M = 0;
-      agpr_epilogue<EPI, false>(h, m0, n0, wm, wn, l15, q4, p0);
-    } else
-#endif
+    epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
+    kstep(std::false_type{}, sa0);
     if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
     else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
-    probe(t, 2);
-    if (DEV & (32 | 64)) { dcount = 0; pm0 = m0; pn0 = n0; }
     c_s += nwl;
     // the next tile's first fragments again, AFTER the epilogue: the copies read in the last [B] are dead here, so
     // nothing but the staging registers stays live across the epilogue (stale data after the last tile, never used)
@@ -267,82 +186,26 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a7_kernel(GemmArgs g, int ti
     read_a(nbuf, 0, fa0);
     read_w_all(nbuf, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    probe(t, 3);
   }
-#ifdef TSPO_DEV_HOOKS
-  if ((DEV & 128) && lane == 0) {
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos)) + ((size_t)blockIdx.x * 4 + wid) * 3;
-    o[0] = bar_cycles; o[1] = ks_cycles; o[2] = ks_count;
-  }
-#endif
 }
 
 
-template <int EPI, bool A2, bool PRE0, bool RW = false, int DEV = 0>
+template <int EPI>
 int launch_gemm_a7(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
   g.tilesN = (g.N + G3_BN - 1) / G3_BN;
   g.nwg = tilesM * g.tilesN;
   int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
   if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
-  hipLaunchKernelGGL((gemm_bf16_a7_kernel<EPI, A2, PRE0, RW, DEV>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
+  hipLaunchKernelGGL((gemm_bf16_a7_kernel<EPI>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
   return tspo::check_launch("gemm_bf16_a7");
 }
-}  // namespace
 
-#ifdef TSPO_DEV_HOOKS
-static void* g_dev_debug = nullptr;
-extern "C" void tspo_dev_set_debug(void* p) { g_dev_debug = p; }
-static void* tspo_dev_debug_ptr() { return g_dev_debug; }
-#endif
-
-namespace {
 template <int EPI>
 int launch_a7_variant(const GemmArgs& g, hipStream_t st) {
   if ((g.K / GT_BK) % 2 != 0 || g.K < 2 * GT_BK)
     return tspo::set_err(TSPO_EINVAL, "gemm_agpr: K=%d must be a multiple of 128", g.K);
-#ifdef TSPO_DEV_HOOKS
-  if (g.variant == 83) return launch_gemm_a7<EPI, true, false>(g, st);    // A/B: A two K-steps ahead, no early epilogue prefetch
-  if (g.variant == 84) return launch_gemm_a7<EPI, false, true, true>(g, st);   // A/B: relaxed waits between [B] and the next [A]
-  if (g.variant == 85) {                                                  // tile-phase probe (s_memtime): needs tspo_dev_set_debug()
-    GemmArgs h = g;
-    h.pos = reinterpret_cast<const float*>(tspo_dev_debug_ptr());
-    if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_agpr: variant 85 without a debug buffer");
-    return launch_gemm_a7<EPI, false, true, false, 1>(h, st);
-  }
-  if (g.variant == 88) return launch_gemm_a7<EPI, false, true, false, 2>(g, st);   // staggered start, 6.4 us across an XCD's workgroups
-  if (g.variant == 89) return launch_gemm_a7<EPI, false, true, false, 4>(g, st);   // staggered start, 12.8 us
-  if (g.variant == 90) {                                                  // tile-phase probe of the staggered kernel
-    GemmArgs h = g;
-    h.pos = reinterpret_cast<const float*>(tspo_dev_debug_ptr());
-    if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_agpr: variant 90 without a debug buffer");
-    return launch_gemm_a7<EPI, false, true, false, 5>(h, st);
-  }
-  if (g.variant == 81) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true>(h, st); }   // slice 1 of every tile not stored
-  if (g.variant == 78) {                                                  // K-step wait/barrier probe: needs tspo_dev_set_debug()
-    GemmArgs h = g;
-    h.pos = reinterpret_cast<const float*>(tspo_dev_debug_ptr());
-    if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_agpr: variant 78 without a debug buffer");
-    return launch_gemm_a7<EPI, false, true, false, 128>(h, st);
-  }
-  if (g.variant == 79) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true, false, 64>(h, st); }   // ... one store per K-step
-  if (g.variant == 80) { GemmArgs h = g; h.P = -3; return launch_gemm_a7<EPI, false, true, false, 32>(h, st); }   // ... and stored (dummy data) from the next tile's first two K-steps
-  if (g.variant >= 91 && g.variant <= 94) {   // epilogue entry de-phased by 128 / 256 / 512 / 1024 cycles per wave
-    GemmArgs h = g;
-    h.P = -9 - (2 << (g.variant - 91));
-    return launch_gemm_a7<EPI, false, true>(h, st);
-  }
-  if (g.variant == 95) return launch_gemm_a7<EPI, false, true, false, 8>(g, st);    // timing only: W addressed as 1 KB blocks
-  if (g.variant == 96) return launch_gemm_a7<EPI, false, true, false, 24>(g, st);   // timing only: W and A addressed as 1 KB blocks
-  if (g.variant == 97 || g.variant == 98 || g.variant == 99) {   // N groups per XCD set: 1 / 4 / 8 (shipped: 2 for wide N)
-    GemmArgs h = g;
-    h.ngrp = g.variant == 97 ? 1 : (g.variant == 98 ? 4 : 8);
-    return launch_gemm_a7<EPI, false, true>(h, st);
-  }
-  if (g.variant == 86) { GemmArgs h = g; h.P = -1; return launch_gemm_a7<EPI, false, true>(h, st); }   // epilogue without memory traffic
-  if (g.variant == 87) { GemmArgs h = g; h.P = -2; return launch_gemm_a7<EPI, false, true>(h, st); }   // epilogue to / from one hot tile per workgroup
-#endif
-  return launch_gemm_a7<EPI, false, true>(g, st);
+  return launch_gemm_a7<EPI>(g, st);
 }
 }  // namespace
 

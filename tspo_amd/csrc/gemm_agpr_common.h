@@ -7,14 +7,6 @@
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-// Development hooks (python -m tspo_amd.build --dev only): epilogue ablations selected at run time through GemmArgs.P and
-// an s_memtime probe of the tile phases (DEV bit 0 of the kernel template).  The shipped library compiles none of it.
-#ifdef TSPO_DEV_HOOKS
-#define A7_ABL(g, n) ((g).P == -(n))
-#else
-#define A7_ABL(g, n) false
-#endif
-
 namespace {
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -84,12 +76,6 @@ template <int EPI, bool FULL>
 __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0, int wm, int wn, int l15, int q4,
                                               const EpiPre& p0) {
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first v_accvgpr_read
-#ifdef TSPO_DEV_HOOKS
-  if (g.P <= -10) {   // A/B: the four waves enter the epilogue (-P - 9) x 64 cycles apart instead of in lock-step
-    const int w = wm * 2 + wn;
-    for (int i = 0; i < w * (-g.P - 9); ++i) __builtin_amdgcn_s_sleep(1);
-  }
-#endif
   constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
   constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
   float2 rst[8];
@@ -136,13 +122,6 @@ __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0,
         }
         if (nhs == 0) rload(mi, wn * 2 + 1);
       }
-#ifdef TSPO_DEV_HOOKS
-      if (nhs == 1 && A7_ABL(g, 3)) {   // ablation: slice 1 computed but not stored (what deferring its stores could save)
-        GemmArgs h = g;
-        h.M = 0;
-        g3_epi_row<EPI, true, false>(h, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
-      } else
-#endif
       g3_epi_row<EPI, true, FULL>(g, vv, p.ec, rst[mi], m0 + wm * 128 + mi * 16 + l15, n0, ws, q4, nullptr, rp);
     });
   });

@@ -1,0 +1,263 @@
+// Internal: the LDS-DMA operand-path GEMM kernel ("a9") as a template - instantiated by gemm_dma.hip (production schedule) and,
+// in --dev builds, by dev/gemm_dma_lab.hip (schedule A/Bs, the no-DMA ablation, the s_memtime probe).
+#pragma once
+#include "gemm_agpr_common.h"
+
+namespace {
+// ===========================================================================
+// "a9": the same tile, wave layout, AGPR accumulators and epilogue as a7, but the operands reach LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds) in the schedule of the vendor library's hand-written 256x256x64 kernel for this chip
+// (hipBLASLt `Custom_Cijk_Alik_Bljk_BBS_..._MT256x256x64_MI16x16x1`, read from its disassembly as a specification;
+// DESIGN 4.4): the WHOLE K-step's fragments live in registers (4 x 32 VGPRs), so a ring buffer can be refilled two stages
+// ahead as soon as its second K-half has been read into registers - no staging VGPRs, no ds_write, 16 instead of 32 staging
+// instructions per wave and K-step:
+//   K-step it (buffer cb = it & 1 holds stage it, nb stage it+1 in flight, fa0/fw0 = K-half 0 of stage it):
+//     K-half 0 MFMAs | A fragments of K-half 1 <- cb | B1 | DMA A(it+2) -> cb.A, W fragments of K-half 1 <- cb | B2 |
+//                    DMA A(it+2) rest, DMA W(it+2) -> cb.W
+//     K-half 1 MFMAs | DMA W(it+2) | vmcnt(n): stage it+1 landed, B3 | fragments of K-half 0 of stage it+1 <- nb
+// The XOR swizzle of the LDS image (chunk c of row r at c ^ (r & 7)) is applied on the global SOURCE address (an LDS-DMA
+// destination is lane-linear).  DMA instructions are inline asm: hipcc's wait-count pass does not see them, so its own
+// vmcnt waits (epilogue loads / stores) can only over-wait, and the three waits that order DMA against the fragment reads
+// are written here explicitly.
+//
+// WHAT goes into WHICH of the 128 gaps between a K-step's MFMAs is a compile-time table (A9Sched): a wave alone on its SIMD
+// hides about three issue slots per 16-cycle MFMA, and the measured cost of a K-step follows the densest stretch of its
+// memory instructions, not their number (a one-barrier schedule with 32 memory instructions behind 32 consecutive MFMAs ran
+// 5-8 % slower than this one with three barriers; s_memtime probe: the barriers cost 20-40 cycles each, the vmcnt wait 0).
+enum : int {
+  OP_NONE = 0,
+  OP_RA1 = 1,    // +j: A fragment j of K-half 1 <- current buffer
+  OP_RW1 = 9,    // +j: W fragment j of K-half 1 <- current buffer
+  OP_RA0 = 17,   // +j: A fragment j of K-half 0 of the NEXT stage <- other buffer
+  OP_RW0 = 25,
+  OP_MA = 33,    // +j: m0 <- LDS address of A piece j
+  OP_DA = 41,    // +j: DMA of A piece j (m0 set by the OP_MA before it)
+  OP_MW = 49,
+  OP_DW = 57,
+  OP_MDA = 65,   // +j: m0 and DMA in the same gap
+  OP_MDW = 73,
+  OP_B1 = 81, OP_B2 = 82, OP_B3 = 83
+};
+struct A9Sched {
+  signed char op[128];   // gap after MFMA i of the K-step (0-63: K-half 0, 64-127: K-half 1)
+  int vm;                // DMAs of this K-step issued before B3 (-> s_waitcnt vmcnt(vm) waits for the previous K-step's only)
+};
+constexpr A9Sched a9_sched(int s) {
+  A9Sched t{};
+  auto put = [&](int gap, int op) { t.op[gap] = (signed char)op; };
+  if (s == 0) {   // the vendor kernel's positions, m0 and DMA in one gap
+    for (int j = 0; j < 8; ++j) put(2 * j, OP_RA1 + j);
+    put(21, OP_B1);
+    for (int j = 0; j < 5; ++j) { put(22 + 2 * j, OP_MDA + j); put(23 + 2 * j, OP_RW1 + j); }
+    put(33, OP_RW1 + 5); put(35, OP_RW1 + 6); put(37, OP_RW1 + 7);
+    put(47, OP_B2);
+    put(48, OP_MDA + 5); put(51, OP_MDA + 6); put(54, OP_MDA + 7); put(57, OP_MDW + 0); put(60, OP_MDW + 1);
+    put(64 + 2, OP_MDW + 2); put(64 + 6, OP_MDW + 3); put(64 + 10, OP_MDW + 4);
+    put(64 + 20, OP_B3);
+    put(64 + 24, OP_MDW + 5); put(64 + 28, OP_MDW + 6); put(64 + 55, OP_MDW + 7);
+    const int ra[8] = {21, 22, 23, 25, 26, 29, 31, 32}, rw[8] = {33, 34, 37, 40, 42, 45, 48, 51};
+    for (int j = 0; j < 8; ++j) { put(64 + ra[j], OP_RA0 + j); put(64 + rw[j], OP_RW0 + j); }
+  } else if (s == 4) {   // DMA spread evenly: one every 6 gaps from B1 to the end of the K-step
+    for (int j = 0; j < 8; ++j) put(2 * j, OP_RA1 + j);
+    put(21, OP_B1);
+    for (int j = 0; j < 8; ++j) put(23 + 2 * j, OP_RW1 + j);
+    put(22, OP_MDA + 0); put(28, OP_MDA + 1); put(34, OP_MDA + 2); put(40, OP_MDA + 3);
+    put(47, OP_B2);
+    put(48, OP_MDA + 4); put(54, OP_MDW + 0); put(60, OP_MDA + 5); put(66, OP_MDW + 1); put(72, OP_MDA + 6); put(78, OP_MDW + 2);
+    put(84, OP_MDA + 7);
+    put(85, OP_B3);
+    for (int j = 0; j < 8; ++j) { put(86 + 2 * j, OP_RA0 + j); put(102 + 2 * j, OP_RW0 + j); }
+    put(91, OP_MDW + 3); put(97, OP_MDW + 4); put(103, OP_MDW + 5); put(109, OP_MDW + 6); put(115, OP_MDW + 7);
+  }
+  for (int i = 0; i < 128 && t.op[i] != OP_B3; ++i)
+    if ((t.op[i] >= OP_DA && t.op[i] < OP_MW) || (t.op[i] >= OP_DW && t.op[i] < OP_MDA) || (t.op[i] >= OP_MDA && t.op[i] < OP_B1)) ++t.vm;
+  return t;
+}
+
+template <int EPI, int SCHED, bool PROBE = false>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int tilesM, int ngrp) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE];  // the ONLY LDS object
+  constexpr A9Sched SC = a9_sched(SCHED % 100);
+  constexpr bool NODMA = SCHED >= 100;   // ablation (--dev builds, wrong results): the same stream without its DMA instructions
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int nk = g.K / GT_BK;   // >= 2
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, nwl = gridDim.x >> 3;
+  const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
+  const int panels = (tilesM - pset + npset - 1) / npset;
+  const int ntile_x = panels * n_per;
+  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
+  if (my_tiles == 0) return;
+  A4_FENCE();   // claims a[0:255] for this kernel
+
+  // ---- LDS-DMA: piece P = wid*8 + q of a region = rows 8P..8P+7 (1 KB); lane (rin, slot) brings global chunk slot ^ rin.
+  //      Address split: voffset = lane part + K-step (ONE v_add per K-step), soffset = piece (loop-invariant SGPRs, the same
+  //      for A and W), m0 = LDS destination (one s_add with a literal per piece) ----
+  const int rin = lane >> 3, slot = lane & 7;
+  unsigned lane_goff = ((unsigned)rin * (unsigned)g.K + (unsigned)((slot ^ rin) << 3)) * 2u;
+  unsigned piece_stride = 8u * (unsigned)g.K * 2u;
+  unsigned lds0 = (unsigned)(size_t)lds + (unsigned)wid * 8192u;
+  unsigned soff0 = (unsigned)wid * 8u * piece_stride;
+  int d_kt = 0, d_s = wl;   // the stage the NEXT K-step's DMA brings: K-step inside the tile, tile
+  auto rsrc_a = [&](int s_) {
+    const int m0 = ((s_ / n_per) * npset + pset) * G3_BM;
+    const long r = m0 < g.M ? ((long)(g.M - m0) * g.K * 2) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)(m0 < g.M ? m0 : 0) * g.K), 0,
+                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
+  };
+  auto rsrc_w = [&](int s_) {
+    const int n0 = (grp * n_per + s_ % n_per) * G3_BN;
+    const long r = n0 < g.N ? ((long)(g.N - n0) * g.K * 2) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)(n0 < g.N ? n0 : 0) * g.K), 0,
+                                             (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t a_rs = rsrc_a(d_s), w_rs = rsrc_w(d_s);
+  auto adv_d = [&]() {
+    if (++d_kt == nk) {
+      asm volatile("" ::: "memory");   // keeps the tile switch (two divisions, two descriptors) a BRANCH: if-converted it runs every K-step
+      d_kt = 0; d_s += nwl; a_rs = rsrc_a(d_s); w_rs = rsrc_w(d_s);
+    }
+  };
+  // (named copies inside the lambdas: clang does not capture a variable that only an asm operand uses)
+  auto set_m0 = [&](auto q_, auto isw_, unsigned bufbase) {
+    constexpr int off = decltype(q_)::value * 1024 + (decltype(isw_)::value ? G3_BM * 128 : 0);
+    const unsigned b = bufbase;
+    if (!NODMA) asm volatile("s_add_u32 m0, %0, %1" ::"s"(b), "i"(off) : "scc");
+  };
+  auto dma = [&](auto q_, auto isw_, unsigned voff) {
+    constexpr int q = decltype(q_)::value;
+    constexpr bool isw = decltype(isw_)::value;
+    const unsigned vo = voff, so = soff0 + q * piece_stride;
+    const __amdgpu_buffer_rsrc_t rs = isw ? w_rs : a_rs;
+    if (!NODMA) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so) : "memory");
+  };
+
+  // ---- fragments: both K-halves of a stage, A and W: 4 x 8 x 4 VGPRs ----
+  const int sw = l15 & 7;
+  const int fbaseA = (wm * 128 + l15) * 128, fbaseW = G3_BM * 128 + (wn * 128 + l15) * 128;
+  const int co0 = (q4 ^ sw) << 4, co1 = ((4 + q4) ^ sw) << 4;
+  i32x4 fa0[8], fa1[8], fw0[8], fw1[8];
+  auto ldfrag = [&](const char* p) { return *reinterpret_cast<const i32x4*>(p); };
+
+  // ---- prologue: stages 0 and 1 in flight, stage 0 landed, its K-half 0 in registers ----
+  sfor<0, 2>([&](auto b_) {
+    const unsigned vo = lane_goff + (unsigned)d_kt * (GT_BK * 2u), bb = lds0 + decltype(b_)::value * G3_STAGE;
+    sfor<0, 8>([&](auto q_) {
+      set_m0(q_, std::false_type{}, bb); dma(q_, std::false_type{}, vo);
+      set_m0(q_, std::true_type{}, bb); dma(q_, std::true_type{}, vo);
+    });
+    adv_d();
+  });
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(lds + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(lds + fbaseW + i * 2048 + co0); }
+
+  int it = 0, c_s = wl;
+  // PROBE (--dev builds, csrc/dev/gemm_dma_lab.hip): s_memtime cycles per K-step and inside each synchronisation point, summed per wave
+  unsigned long long pr_ks = 0, pr_n = 0, pr_b1 = 0, pr_b2 = 0, pr_vm = 0, pr_b3 = 0, pr_vmz = 0, pr_nz = 0, pr_vm1 = 0, pr_epi = 0, pr_tile = 0;
+  int pr_kt = 0;
+  auto stamp = [&]() {
+    unsigned long long t = 0;
+    if (PROBE) { t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    return t;
+  };
+  auto kstep = [&](auto zero_, auto last_) {
+    constexpr bool ZERO = decltype(zero_)::value, LAST = decltype(last_)::value;
+    const int cb = it & 1;
+    const unsigned long long pr_t0 = stamp();
+    const char* cur = lds + cb * G3_STAGE;
+    const char* nxt = lds + (cb ^ 1) * G3_STAGE;
+    const unsigned vo = lane_goff + (unsigned)d_kt * (GT_BK * 2u), bb = lds0 + (unsigned)cb * G3_STAGE;
+    sfor<0, 16>([&](auto grp8_) {   // 16 groups of 8 MFMAs: column tile nn = grp8 & 7 of K-half grp8 >> 3
+      constexpr int kh = decltype(grp8_)::value >> 3, nn = decltype(grp8_)::value & 7;
+      sfor<0, 8>([&](auto mi_) {
+        constexpr int mi = decltype(mi_)::value;
+        constexpr int gap = kh * 64 + nn * 8 + mi;
+        constexpr int op = SC.op[gap];
+        {
+          const i32x4 wf = kh ? fw1[nn] : fw0[nn], af = kh ? fa1[mi] : fa0[mi];
+          if (ZERO && kh == 0) A4_MFMA_Z(nn, mi, wf, af); else A4_MFMA(nn, mi, wf, af);
+        }
+        if constexpr (op >= OP_RA1 && op < OP_RA1 + 8) fa1[op - OP_RA1] = ldfrag(cur + fbaseA + (op - OP_RA1) * 2048 + co1);
+        if constexpr (op >= OP_RW1 && op < OP_RW1 + 8) fw1[op - OP_RW1] = ldfrag(cur + fbaseW + (op - OP_RW1) * 2048 + co1);
+        if constexpr (!LAST && op >= OP_RA0 && op < OP_RA0 + 8) fa0[op - OP_RA0] = ldfrag(nxt + fbaseA + (op - OP_RA0) * 2048 + co0);
+        if constexpr (!LAST && op >= OP_RW0 && op < OP_RW0 + 8) fw0[op - OP_RW0] = ldfrag(nxt + fbaseW + (op - OP_RW0) * 2048 + co0);
+        if constexpr (op >= OP_MA && op < OP_MA + 8) set_m0(std::integral_constant<int, op - OP_MA>{}, std::false_type{}, bb);
+        if constexpr (op >= OP_DA && op < OP_DA + 8) dma(std::integral_constant<int, op - OP_DA>{}, std::false_type{}, vo);
+        if constexpr (op >= OP_MW && op < OP_MW + 8) set_m0(std::integral_constant<int, op - OP_MW>{}, std::true_type{}, bb);
+        if constexpr (op >= OP_DW && op < OP_DW + 8) dma(std::integral_constant<int, op - OP_DW>{}, std::true_type{}, vo);
+        if constexpr (op >= OP_MDA && op < OP_MDA + 8) {
+          set_m0(std::integral_constant<int, op - OP_MDA>{}, std::false_type{}, bb);
+          dma(std::integral_constant<int, op - OP_MDA>{}, std::false_type{}, vo);
+        }
+        if constexpr (op >= OP_MDW && op < OP_MDW + 8) {
+          set_m0(std::integral_constant<int, op - OP_MDW>{}, std::true_type{}, bb);
+          dma(std::integral_constant<int, op - OP_MDW>{}, std::true_type{}, vo);
+        }
+        if constexpr (op == OP_B1 || op == OP_B2) {   // every wave holds its A (B1) / W (B2) fragments of this stage -> region may be refilled
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long ta = stamp();
+          asm volatile("s_barrier" ::: "memory");
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          if (PROBE) { if (op == OP_B1) pr_b1 += stamp() - ta; else pr_b2 += stamp() - ta; }
+        }
+        if constexpr (op == OP_B3) {   // this wave's pieces of stage it+1 have landed (SC.vm younger DMAs may fly) -> everybody's
+          const unsigned long long ta = stamp();
+          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SC.vm) : "memory");
+          const unsigned long long tb = stamp();
+          asm volatile("s_barrier" ::: "memory");
+          if (PROBE) {
+            const unsigned long long tc = stamp(); pr_vm += tb - ta; pr_b3 += tc - tb;
+            if (ZERO) { pr_vmz += tb - ta; ++pr_nz; }
+            if (pr_kt == 1) pr_vm1 += tb - ta;
+          }
+        }
+      });
+      A4_FENCE();
+    });
+    adv_d();
+    ++it;
+    if (PROBE) { pr_ks += stamp() - pr_t0; ++pr_n; pr_kt = LAST ? 0 : pr_kt + 1; }
+  };
+
+  for (int t = 0; t < my_tiles; ++t) {
+    const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
+    const unsigned long long pr_tt0 = stamp();
+    kstep(std::true_type{}, std::false_type{});
+    for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
+    EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
+    epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
+    kstep(std::false_type{}, std::true_type{});
+    const unsigned long long pr_te0 = stamp();
+    if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
+    else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
+    if (PROBE) pr_epi += stamp() - pr_te0;
+    c_s += nwl;
+    const char* nbuf = lds + (it & 1) * G3_STAGE;              // the next tile's first fragments, behind the epilogue
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(nbuf + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(nbuf + fbaseW + i * 2048 + co0); }
+    if (PROBE) pr_tile += stamp() - pr_tt0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two stages requested past the last tile (zero-length resources)
+  if (PROBE && lane == 0 && g.pos) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos)) + ((size_t)blockIdx.x * 4 + wid) * 12;
+    o[9] = pr_epi; o[10] = pr_tile; o[11] = (unsigned long long)my_tiles;
+    o[0] = pr_ks; o[1] = pr_n; o[2] = pr_b1; o[3] = pr_b2; o[4] = pr_vm; o[5] = pr_b3; o[6] = pr_vmz; o[7] = pr_nz; o[8] = pr_vm1;
+  }
+}
+
+template <int EPI, int SCHED, bool PROBE = false>
+int launch_gemm_a9(GemmArgs g, hipStream_t st) {
+  const int tilesM = (g.M + G3_BM - 1) / G3_BM;
+  g.tilesN = (g.N + G3_BN - 1) / G3_BN;
+  g.nwg = tilesM * g.tilesN;
+  int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
+  if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
+  hipLaunchKernelGGL((gemm_bf16_a9_kernel<EPI, SCHED, PROBE>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
+  return tspo::check_launch("gemm_bf16_a9");
+}
+
+
+}  // namespace

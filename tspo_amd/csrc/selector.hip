@@ -1326,9 +1326,6 @@ struct SelWs {  // workspace layout shared by forward and backward
 // at one-SIMD-per-wave speed, so the makespan is set by how evenly tiles*S workgroups fill 256 CUs: pick the S (chunk
 // of >= 128 rows, at most 16 partial planes) that wastes the least of the last "round" for both the DxD and 3DxD GEMMs.
 int split_for(int BT, int D) {
-#ifdef TSPO_DEV_HOOKS
-  if (const char* e = getenv("TSPO_SEL_SPLIT")) return atoi(e);
-#endif
   int smax = BT / 128;
   smax = smax < 1 ? 1 : (smax > 16 ? 16 : smax);
   const int tiles = ((D + 127) / 128) * ((D + 127) / 128);
