@@ -8,7 +8,7 @@
 for round in 1 2; do
   for v in "$@"; do
     cp tmp_ab/lib_$v.so tspo_amd/libtspo_hip.so
-    timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rollouts --no-pruned | python -c "
+    timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rollouts --no-pruned --no-720p --no-comm-probe | python -c "
 import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', j['value'], j['roofline']['achieved'], j['roofline']['breakdown_ms'])"
   done
 done

@@ -442,14 +442,16 @@ __device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const 
         nf1 = *reinterpret_cast<const bf16x8*>(kb + (j + 1) * 2048 + (((4 + q4) ^ ksw) << 4));
       }
       const bool live = b * KT + j <= 16;   // wave-uniform
+      // the two K-halves of a score tile are a dependent MFMA pair: issue the first halves of all NQ query tiles, then the
+      // second halves, so that a dependent MFMA follows its producer NQ issue slots later, not back to back
 #pragma unroll
       for (int n = 0; n < NQ; ++n) {
         sc[n][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (live) {
-          sc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[n][0], sc[n][j], 0, 0, 0);
-          sc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[n][1], sc[n][j], 0, 0, 0);
-        }
+        if (live) sc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[n][0], sc[n][j], 0, 0, 0);
       }
+#pragma unroll
+      for (int n = 0; n < NQ; ++n)
+        if (live) sc[n][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[n][1], sc[n][j], 0, 0, 0);
       if (b * KT + j >= 16) {   // key tile 16: only key 256 (row 0 of the tile) exists; tile 17: nothing
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
@@ -584,12 +586,22 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
       const int qrow = (wid * 4 + n) * 16 + l15;
       const float inv = 1.f / l4[n];
       bf16_t* orow = out + (f * S + qrow) * (size_t)C + (size_t)h * 64;
+      // 16-byte stores (round 4: 13.0 -> 12.0 ms per forward on the same box): v_permlane16_swap exchanges the odd 16-lane rows
+      // of d-tile 2p with the even rows of d-tile 2p+1, after which lane row q4 holds 8 consecutive d of tile 2p + (q4 & 1) at
+      // (q4 >> 1) * 8 - half as many store instructions (the store tail of the epilogue is issue-bound; same pairing as the GEMM's)
+      uint2 pk[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        uint2 pk;
-        pk.x = pack_bf16x2(o4[n][dt][0] * inv, o4[n][dt][1] * inv);
-        pk.y = pack_bf16x2(o4[n][dt][2] * inv, o4[n][dt][3] * inv);
-        *reinterpret_cast<uint2*>(orow + dt * 16 + q4 * 4) = pk;
+        pk[dt].x = pack_bf16x2(o4[n][dt][0] * inv, o4[n][dt][1] * inv);
+        pk[dt].y = pack_bf16x2(o4[n][dt][2] * inv, o4[n][dt][3] * inv);
+      }
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const auto w0 = __builtin_amdgcn_permlane16_swap(pk[2 * pr].x, pk[2 * pr + 1].x, false, false);
+        const auto w1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr].y, pk[2 * pr + 1].y, false, false);
+        uint4 st;
+        st.x = w0[0]; st.y = w1[0]; st.z = w0[1]; st.w = w1[1];
+        *reinterpret_cast<uint4*>(orow + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8) = st;
       }
     }
   }
@@ -626,7 +638,9 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
 // Measured and gone from the tree (results: profiles/r2_d_attn_ablation.json, r2_e_attn_persistent_ab.json; code: git
 // history up to 99eb127): a persistent 8-wave form with LDS-DMA double-buffered staging (15.0-15.9 ms per forward on every box
 // against 12.6-14.0 for the kernel above: its two-tiles-per-wave math phase is slower), an 8-wave / 2-tile form at <= 128
-// registers (17.3 ms), a two-pass softmax (30.9 ms), staging-only / math-only ablation builds.
+// registers (17.3 ms), a two-pass softmax (30.9 ms), staging-only / math-only ablation builds; round 4: K and V staged by LDS-DMA
+// into [288][128 B] swizzled rows (no staging registers, no ds_write): 15.1 ms against 12.0 on the same box - the row-major V image
+// costs the P V phase more (ds_read_b64_tr_b16 bank conflicts the [32 keys][16 d] sub-tiles avoid) than the staging saves.
 
 // ===========================================================================
 struct ClipWs {
