@@ -13,7 +13,7 @@ BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pruned"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err)
 python tools/rocpd_summary.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_trace.txt
 head -12 $OUT/kernel_trace.txt
-PMCBENCH="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pruned --no-rollouts --no-profile"
+PMCBENCH="python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pruned --no-rollouts --no-profile --no-720p --no-comm-probe"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -o p -- $PMCBENCH > /dev/null 2> $OUT/pmc_f.err)
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -o p -- $PMCBENCH > /dev/null 2> $OUT/pmc_w.err)
 python tools/pmc_traffic.py $(find $OUT/pmc_f -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_w -name "*counter_collection.csv" | head -1) gemm_bf16_a9 $OUT/gemm_hbm_traffic.json | head -8
