@@ -11,6 +11,11 @@ template <int EPI>
 int lab_variant(const GemmArgs& g, hipStream_t st) {
   if (g.variant == 76) return launch_gemm_a9<EPI, 0>(g, st);     // the vendor kernel's positions
   if (g.variant == 75) return launch_gemm_a9<EPI, 104>(g, st);   // production schedule without its DMA instructions (timing only)
+  if (g.variant == 73 || g.variant == 72 || g.variant == 71) {     // production schedule, N groups per XCD set forced to 1 / 4 / 8 (auto: 2 for wide N)
+    GemmArgs h = g;
+    h.ngrp = g.variant == 73 ? 1 : (g.variant == 72 ? 4 : 8);
+    return launch_gemm_a9<EPI, 4>(h, st);
+  }
   if (g.variant == 74) {                                         // production schedule with the s_memtime probe
     GemmArgs h = g;
     h.pos = reinterpret_cast<const float*>(g_dma_debug);
