@@ -549,6 +549,30 @@ def test_gemm_bf16_persistent_kernel_full_check(N, K):
         np.testing.assert_allclose(out.numpy(), want.numpy(), err_msg=f"variant {variant}", **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(70001, 264, 128), (20011, 1000, 192), (9000, 3000, 320), (66000, 256, 640), (5000, 4096, 128)],
+                         ids=["ragged-N264-K128", "ragged-N1000-K192", "N3000-K320", "N256-K640", "N4096-K128"])
+def test_gemm_dma_kernel_edge_shapes(M, N, K):
+    """The LDS-DMA kernel outside the encoder's shapes: ragged last tiles in M AND N (rows / columns past the matrix are
+    range-checked away by the DMA's buffer descriptors and never stored), the shortest K loops it takes (2, 3 and 5 K-steps:
+    first + last K-step only, one and three middle ones), a single column tile, the widest N - every output element against fp32,
+    bias / residual / gelu epilogues, plus bitwise repeatability (race screen for the two-stage ring at the tile switch)."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    A, W = _bf16r(synth.normal((M, K), 21 + N)), _bf16r(synth.normal((N, K), 22 + K, 0.05))
+    bias = T_(synth.normal((N,), 23, 0.1))
+    R = _bf16r(synth.normal((M, N), 24))
+    ref = A.float() @ W.float().t() + bias
+    Ad, Wd, bd, Rd = A.to(DEV), W.to(DEV), bias.to(DEV), R.to(DEV)
+    tol = dict(rtol=1e-2, atol=2e-2)
+    for what, want, kw in (("bias", ref, {}), ("resid", ref + R.float(), dict(residual=Rd)), ("gelu", O.quick_gelu(ref), dict(act_=1))):
+        act = kw.get("act_", 0) | (77 << 8)
+        out = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=act)
+        np.testing.assert_allclose(out.float().cpu().numpy(), want.numpy(), err_msg=what, **tol)
+        for _ in range(3):
+            assert torch.equal(ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=act), out), what
+        auto = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=kw.get("act_", 0))
+        assert torch.equal(auto, out), f"{what}: the automatic choice for this shape is not the DMA kernel"
+
+
 def test_clip_vit_forward_70_frames_production_kernels():
     """70 frames (M = 17990 rows) is large enough that every encoder GEMM takes the persistent kernel: features vs
     the fp32 oracle on the CPU (bf16-rounded matrices) within the encode tolerance."""
