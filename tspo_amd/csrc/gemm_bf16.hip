@@ -161,7 +161,7 @@ int launch_gemm_v1(GemmArgs g, hipStream_t st) {
 template <int EPI>
 int launch_big(GemmArgs g, hipStream_t st) {
   if (g.variant == 0) g.variant = 77;
-  if (g.variant >= 71 && g.variant < 78) return tspo::gemm_bf16_dma(EPI, g, st);
+  if (g.variant >= 67 && g.variant < 78) return tspo::gemm_bf16_dma(EPI, g, st);
   if (g.variant == 82) return tspo::gemm_bf16_agpr(EPI, g, st);
   return tspo::set_err(TSPO_EINVAL, "gemm: kernel variant %d is not part of this build", g.variant);
 }
