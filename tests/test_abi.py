@@ -77,7 +77,7 @@ def test_shipped_library_has_no_dev_hooks():
     l = _lib.lib()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    for variant in (2, 6, 8, 9, 60, 69, 70, 71, 72, 74, 75, 76, 78, 85):   # retired kernels / ablations / probes and the DMA-kernel lab schedules
+    for variant in (2, 6, 8, 9, 60, 67, 69, 70, 71, 72, 74, 75, 76, 78, 85):   # retired kernels / ablations / probes and the DMA-kernel lab schedules
         assert l.tspo_gemm_bf16(p, p, p, None, p, _lib.TSPO_BF16, 4096, 4096, 1024, variant << 8, None) == -1
         assert b"not part of this build" in l.tspo_last_error(), (variant, l.tspo_last_error())
     blob = open(_lib.LIB_PATH, "rb").read()

@@ -6,7 +6,7 @@ Variants are timed interleaved (rotating order) over several rounds; the median 
 hand-written kernels fuse (tool only; the product never calls it).
 
     python tools/bench_gemm.py T variants rounds        e.g.  1024 82,77,-1 6
-Variants: 77 = production (LDS-DMA operands), 82 = register-staged four-wave kernel, -1 = vendor; 76 / 75 (schedule A/B, no-DMA
+Variants: 77 = production (LDS-DMA operands), 82 = register-staged four-wave kernel, -1 = vendor; 76 / 67 / 75 (three-barrier schedule, vendor positions, no-DMA
 ablation) need a `python -m tspo_amd.build --dev` library.
 Every variant's full output is also compared with the first variant's (bitwise where the K order is the same)."""
 import sys, os, statistics

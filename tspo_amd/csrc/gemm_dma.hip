@@ -10,7 +10,7 @@ namespace {
 template <int EPI>
 int launch_a9_variant(const GemmArgs& g, hipStream_t st) {
   if (g.K < 2 * GT_BK) return tspo::set_err(TSPO_EINVAL, "gemm_dma: K=%d too small for the DMA kernel", g.K);
-  if (g.variant == 77) return launch_gemm_a9<EPI, 9>(g, st);   // production schedule (two barriers per K-step)
+  if (g.variant == 77) return launch_gemm_a9<EPI, A9ScheduleProduction>(g, st);
   if (tspo_lab_gemm_dma) return tspo_lab_gemm_dma(EPI, &g, st);
   return tspo::set_err(TSPO_EINVAL, "gemm: kernel variant %d (epilogue %d) is not part of this build", g.variant, EPI);
 }
