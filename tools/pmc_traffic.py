@@ -2,7 +2,8 @@
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes because the TCC
 block has 4 slots).  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB;
 on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads -> doubled; WRITE_SIZE is
-uncalibrated -> reported raw.  Usage: pmc_traffic.py fetch.csv write.csv kernel_substring [out.json]"""
+reported raw.  Both rules were checked on launches of known byte count in the production
+GEMM's own access pattern (tools/fetch_calibrate.sh, profiles/r4_g_fetch_calibration_and_cache_policy.txt: FETCH_SIZE 0.513, WRITE_SIZE 1.001).  Usage: pmc_traffic.py fetch.csv write.csv kernel_substring [out.json]"""
 import csv, json, sys, collections
 
 

@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
     constexpr bool isw = decltype(isw_)::value;
     const unsigned vo = voff, so = soff0 + q * piece_stride;
     const __amdgpu_buffer_rsrc_t rs = isw ? w_rs : a_rs;
+    // default cache policy on purpose: `nt` on the A or the W stream cuts the QKV form's L2-side fetch by a third (3.7 -> 2.5 GB per
+    // launch) and is 2-6 % SLOWER on every shape; sc1 / sc0 sc1 change nothing (profiles/r4_g_fetch_calibration_and_cache_policy.txt)
     if (!NODMA) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so) : "memory");
   };
 
