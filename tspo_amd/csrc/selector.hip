@@ -147,26 +147,30 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 // One workgroup = 64 x (32*WN) outputs, NWM x 2 waves of (64/NWM) x (16*WN); 3-deep ring with counted vmcnt waits.
 // WN = 3 (64x96 tiles) is used when N % 96 == 0: for D = 768 that makes BT=2048 x 768 exactly 256 workgroups (one
 // per CU) and x 2304 exactly 3 per CU, instead of 1.5 / 4.5 with 64x64 tiles, and gives 48 MFMAs per barrier.
-template <int WN, int NT_NST>
-constexpr int nt_lds_bytes() { return NT_NST * (8 + 4 * WN) * 1024; }
+// Small-M form (BM = 32: NWM = 2, MI = 1, four waves): with BT = 512 rows - one prompt per micro-step, the reference's training
+// configuration - 64-row tiles give 64 (DxD) or 192 (Dx3D) workgroups for 256 CUs and the launch takes one workgroup's 24 K-steps
+// (26-27 us whatever N is); 32-row tiles spread the same MFMAs over 2-4x as many CUs.
+template <int WN, int NT_NST, int BM = 64>
+constexpr int nt_lds_bytes() { return NT_NST * (BM / 8 + 4 * WN) * 1024; }
 
 // (body of the kernel: also instantiated inside dgrad_wgrad_kernel, which runs it next to a weight-gradient tile set)
-template <int EPI, int WN, int NWM, int NT_NST, int SPLIT>
+template <int EPI, int WN, int NWM, int NT_NST, int SPLIT, int MI = 4 / NWM>
 __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __restrict__ A, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ R,
                                                      float* __restrict__ C, int M, int N, int K, int bx, int by) {
   constexpr int NW = NWM * 2;                  // waves: NWM along M x 2 along N
-  constexpr int MI = 4 / NWM;                  // 16-row tiles per wave (64 rows / NWM / 16)
+  constexpr int BM = 16 * NWM * MI;            // A rows per slab (MI = 16-row tiles per wave): 64, or 32 in the small-M form
+  constexpr int AP = BM / 8;                   // 1 KB DMA pieces of the A part
   constexpr int BN = 32 * WN;                  // W rows per slab
-  constexpr int PIECES = 8 + BN / 8;           // 1 KB DMA pieces per slab (A: 8, W: BN/8)
+  constexpr int PIECES = AP + BN / 8;          // 1 KB DMA pieces per slab (A: BM/8, W: BN/8)
   constexpr int PW_HI = (PIECES + NW - 1) / NW, PW_LO = PIECES / NW;   // first NHI waves move PW_HI pieces, the rest PW_LO
   constexpr int NHI = PIECES - PW_LO * NW;     // (0 when it divides evenly)
   constexpr int SLAB = PIECES * 1024;          // ring of (A 64x128 B | W BNx128 B)
-  static_assert(NT_NST * SLAB == nt_lds_bytes<WN, NT_NST>(), "LDS size");
+  static_assert(NT_NST * SLAB == nt_lds_bytes<WN, NT_NST, BM>(), "LDS size");
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int l15 = lane & 15, q = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = by * 64, n0 = bx * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const int nk = K >> 5;
   const int rin = lane >> 3, slot = lane & 7;
   const bool hi = NHI == 0 || wid < NHI;
@@ -178,12 +182,12 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
       if (p < PW_LO || hi) {
         const int piece = piece0 + p;            // wave-uniform
         const float* src;
-        if (piece < 8) {
+        if (piece < AP) {
           int gr = m0 + piece * 8 + rin;
           gr = gr < M ? gr : M - 1;
           src = A + (size_t)gr * K;
         } else {
-          src = W + (size_t)(n0 + (piece - 8) * 8 + rin) * K;
+          src = W + (size_t)(n0 + (piece - AP) * 8 + rin) * K;
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + kt * 32 + ((slot ^ rin) << 2)),
                                          (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
@@ -218,7 +222,7 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
 #pragma unroll
   for (int i = 0; i < MI; ++i) offA[i] = (wm * 16 * MI + i * 16 + l15) * 128;
 #pragma unroll
-  for (int j = 0; j < WN; ++j) offW[j] = 8192 + (wn * 16 * WN + j * 16 + l15) * 128;
+  for (int j = 0; j < WN; ++j) offW[j] = AP * 1024 + (wn * 16 * WN + j * 16 + l15) * 128;
   const int sw = l15 & 7;
 #pragma unroll
   for (int t = 0; t < NT_NST - 1; ++t)
@@ -294,19 +298,29 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
     }
 }
 
-template <int EPI, int WN, int NWM, int NT_NST, int SPLIT>
+template <int EPI, int WN, int NWM, int NT_NST, int SPLIT, int MI = 4 / NWM>
 __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ R, float* __restrict__ C,
                                                                     int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) char lds[nt_lds_bytes<WN, NT_NST>()];   // the only LDS object
-  gemm_f32_nt_lds_body<EPI, WN, NWM, NT_NST, SPLIT>(lds, A, W, bias, R, C, M, N, K, blockIdx.x, blockIdx.y);
+  __shared__ __attribute__((aligned(16))) char lds[nt_lds_bytes<WN, NT_NST, 16 * NWM * MI>()];   // the only LDS object
+  gemm_f32_nt_lds_body<EPI, WN, NWM, NT_NST, SPLIT, MI>(lds, A, W, bias, R, C, M, N, K, blockIdx.x, blockIdx.y);
 }
 
 template <int EPI, int SPLIT>
 int launch_gemm_nt_p(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
                      hipStream_t st) {
   const int mt = (M + 63) / 64;
+  // small-M form: the 64x96 tiling would leave CUs without a workgroup (BT = 512: 64 / 192 workgroups), so 32x32 tiles (four waves)
+  // spread the MFMAs over every CU: DxD at BT = 512 26 -> 12-13 us, Dx3D 27 -> 25.5 us (4.5 wave-tiles per SIMD: 32x64 / 32x96 /
+  // 64x96 tiles all end at 26-27 us, the CU with one workgroup more sets the time).  Measured and not kept: fragments of slab kt+1
+  // read under the MFMAs of slab kt with the DMA three slabs ahead (12.7-13.7 vs 11.9-13.0 us), a 4-deep ring (same).  Same
+  // contraction order per output element as the large form: bitwise the same results.
+  if (K % 32 == 0 && N % 32 == 0 && (long)(N / 96) * mt < 256) {
+    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 1, 2, 3, SPLIT, 1>), dim3(N / 32, (M + 31) / 32), dim3(256), 0, st, A, W, bias, R, C,
+                       M, N, K);
+    return tspo::check_launch("selector gemm_nt");
+  }
   // ring depth 3 keeps two workgroups (16 waves) per CU; when the grid holds more than two workgroups per CU a 2-deep
   // ring (40 KB) lets three run at once instead of leaving the third for a half-empty second round
   if (K % 32 == 0 && N % 96 == 0) {
@@ -1148,6 +1162,27 @@ __global__ __launch_bounds__(512, 2) void dgrad_wgrad_kernel(const float* __rest
   }
 }
 
+// Small-M form of the launch above (BT = 512: the 64x96 data-gradient tiling has 64 workgroups): 256-thread workgroups, the data
+// gradient in 32x32 tiles (gemm_f32_nt_lds_body<.., WN 1, NWM 2, ring 3, MI 1>), the weight-gradient tiles as four waves of 64x64.
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void dgrad_wgrad_small_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                  const float* __restrict__ R, float* __restrict__ C, int M,
+                                                                  int N, int K, int n_nt,
+                                                                  const float* __restrict__ dY, const float* __restrict__ X,
+                                                                  float* __restrict__ Cp, float* __restrict__ cpart, int cstride,
+                                                                  int NI, int NJ, int chunk) {
+  __shared__ __attribute__((aligned(16))) char lds[3 * 16384];
+  static_assert(nt_lds_bytes<1, 3, 32>() <= 3 * 16384, "LDS");
+  const int b = blockIdx.x;
+  if (b < n_nt) {
+    const int nx = N / 32;
+    gemm_f32_nt_lds_body<EPI, 1, 2, 3, 0, 1>(lds, A, W, nullptr, R, C, M, N, K, b % nx, b / nx);
+  } else {
+    const int t = b - n_nt, tj = NJ >> 7, ti = NI >> 7;
+    gemm_f32_tn_lds_body<4, 3>(lds, dY, X, Cp, cpart, cstride, M, NI, NJ, chunk, t % tj, (t / tj) % ti, t / (tj * ti));
+  }
+}
+
 // Split-precision (bf16x3) version of the weight-gradient GEMM: same 128x128 tile / 4 waves of 64x64 / interleaved
 // feature map, but a slab is 32 contraction rows = one bf16 MFMA k-step: lane (l15, q) owns rows 8q..8q+7, reads them as
 // 8 float4 per operand (4 interleaved feature tiles each), splits every value into hi + lo bf16 and issues
@@ -1455,6 +1490,12 @@ int dgrad_with_wgrad(const float* dY, const float* Wt, const float* R, float* dX
                      hipStream_t st) {
   const int chunk = ((BT + s.S - 1) / s.S + 3) / 4 * 4;
   const int n_nt = (N / 96) * ((BT + 63) / 64), n_tn = (NI / 128) * (NJ / 128) * s.S;
+  if (n_nt < 256 && N % 32 == 0) {   // small-M form (BT = 512: 28 -> 20.5 us per launch)
+    const int n_nt_s = (N / 32) * ((BT + 31) / 32);
+    hipLaunchKernelGGL((dgrad_wgrad_small_kernel<EPI>), dim3(n_nt_s + n_tn), dim3(256), 0, st, dY, Wt, R, dX, BT, N, K, n_nt_s, dYw,
+                       Xw, part, cpart, cstride, NI, NJ, chunk);
+    return tspo::check_launch("selector dgrad+wgrad");
+  }
   hipLaunchKernelGGL((dgrad_wgrad_kernel<EPI>), dim3(n_nt + n_tn), dim3(512), 0, st, dY, Wt, R, dX, BT, N, K, n_nt, dYw, Xw,
                      part, cpart, cstride, NI, NJ, chunk);
   return tspo::check_launch("selector dgrad+wgrad");
