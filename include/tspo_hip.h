@@ -163,8 +163,13 @@ int tspo_selector_backward(const tspo_selector_weights* w, const float* img, con
  * ~1e-5 relative error instead of fp32's ~1e-6) - an opt-in for the TRAINING
  * step, where the reference itself runs in bf16 (`--bf16`,
  * train_deepspeed.sh:33, scripts/zero3.json:10); flags = 0 is identical to the calls
- * above (exact fp32, the mode the greedy-index parity tests use).            */
+ * above (exact fp32, the mode the greedy-index parity tests use).
+ * TSPO_SEL_ACCUMULATE (backward calls only): the gradients are ADDED to what the
+ * gradient buffers hold instead of overwriting them - the second.. micro-step of
+ * a gradient-accumulation window (gradient_accumulation_steps 2,
+ * train_deepspeed.sh:31) without a scratch bucket and an add pass.          */
 #define TSPO_SEL_BF16X3 1
+#define TSPO_SEL_ACCUMULATE 2
 int tspo_selector_forward_ex(const tspo_selector_weights* w, const float* img, const float* txt, const float* clip,
                              int B, int T, int D, int H, int M, int window, float tau,
                              float* scores, float* temporal_attn,

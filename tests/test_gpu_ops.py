@@ -482,6 +482,48 @@ def test_selector_fwd_bwd_bitwise_repeatable():
             assert torch.equal(g, ref_g), f"gradients differ on repetition {it}"
 
 
+def test_selector_small_micro_batch_forms_and_accumulate():
+    """The reference trains with ONE prompt per micro-step and 2 micro-steps per optimizer step (train_deepspeed.sh:30-31).  At
+    B = 1, T = 512, D = 768 the fp32 GEMMs take their small-M forms (32x32 NT tiles; 64x64 weight-gradient tiles that hold the
+    whole contraction and write the FINAL gradient, no partial planes / reduction launch):
+    * forward of a prompt alone == the same prompt inside a B = 4 batch (large 64x96 tiles), bit for bit - every output element keeps
+      its contraction order across tilings;
+    * gradients: repeatable bit for bit (race screen for the K-group exchange through LDS), equal to the B = 4 call's per-prompt sum
+      to rounding, and TSPO_SEL_ACCUMULATE adds exactly (g + g == 2 g) on the final-tile path, the split-reduction path (B = 4) and
+      the bf16x3 path."""
+    B, T, D, H, M, w, tau = 4, 512, 768, 8, 1, 12, 0.025
+    img, txt = G_(synth.normal((B, T, D), 4100)), G_(synth.normal((B, M, D), 4101))
+    clip, ds = G_(synth.normal((B, T), 4102, 0.1)), G_(synth.normal((B, T), 4103, 0.01))
+    flat = flat_from_state(synth.selector_state(D, seed=19, std=0.5 / np.sqrt(D), bias_std=0.05), D)
+    n = ops.trainable_numel(D)
+    s4, h4, ws4 = ops.selector_forward(flat, img, txt, clip, H, w, tau)
+    g4 = torch.zeros_like(flat)
+    ops.selector_backward(flat, g4, img, txt, ds, H, w, tau, ws4)
+    gsum = torch.zeros_like(flat)
+    for b in range(B):
+        sl = slice(b, b + 1)
+        s1, h1, ws1 = ops.selector_forward(flat, img[sl], txt[sl], clip[sl], H, w, tau)
+        assert torch.equal(s1, s4[sl]) and torch.equal(h1, h4[sl]), f"prompt {b}: small-M forward differs from the batched one"
+        g1 = torch.zeros_like(flat)
+        ops.selector_backward(flat, g1, img[sl], txt[sl], ds[sl], H, w, tau, ws1)
+        for _ in range(5):
+            g1b = torch.full_like(flat, float("nan"))          # the final-tile kernels overwrite (no zero-initialised bucket needed)
+            ops.selector_backward(flat, g1b, img[sl], txt[sl], ds[sl], H, w, tau, ws1)
+            assert torch.equal(g1b[:n], g1[:n]), "small-M backward is not repeatable"
+        ops.selector_backward(flat, gsum, img[sl], txt[sl], ds[sl], H, w, tau, ws1, accumulate=True)
+    gmax = g4[:n].abs().max().item()
+    assert gmax > 0 and (gsum[:n] - g4[:n]).abs().max().item() <= 5e-6 * gmax
+    # accumulate adds exactly: once more onto itself
+    for (imgs, txts, clips, dss, prec) in ((img[:1], txt[:1], clip[:1], ds[:1], "fp32"), (img, txt, clip, ds, "fp32"),
+                                           (img[:1], txt[:1], clip[:1], ds[:1], "bf16x3")):
+        _, _, wsx = ops.selector_forward(flat, imgs, txts, clips, H, w, tau, precision=prec)
+        ga = torch.zeros_like(flat)
+        ops.selector_backward(flat, ga, imgs, txts, dss, H, w, tau, wsx, precision=prec)
+        gb = ga.clone()
+        ops.selector_backward(flat, gb, imgs, txts, dss, H, w, tau, wsx, precision=prec, accumulate=True)
+        assert torch.equal(gb[:n], 2 * ga[:n]), f"accumulate is not an exact add ({prec}, B={imgs.shape[0]})"
+
+
 def test_selector_backward_batched_sums():
     """grads of a batch == sum of per-video grads (what the DP all-reduce relies on)."""
     B, T, D, H, M, w, tau = 3, 96, 64, 8, 1, 12, 0.025

@@ -10,6 +10,7 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 // Split-precision operands ("bf16x3"): x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi); a product is
@@ -154,7 +155,9 @@ template <int WN, int NT_NST, int BM = 64>
 constexpr int nt_lds_bytes() { return NT_NST * (BM / 8 + 4 * WN) * 1024; }
 
 // (body of the kernel: also instantiated inside dgrad_wgrad_kernel, which runs it next to a weight-gradient tile set)
-template <int EPI, int WN, int NWM, int NT_NST, int SPLIT, int MI = 4 / NWM>
+// HALVES = 2: the workgroup has 2 x NWM*2 waves and runs TWO tiles side by side (waves 0..NW-1 one, NW..2NW-1 the other: the caller
+// passes each half its own lds / bx / by; the K-loops are the same length, so the workgroup-wide barriers line up).
+template <int EPI, int WN, int NWM, int NT_NST, int SPLIT, int MI = 4 / NWM, int HALVES = 1>
 __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __restrict__ A, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ R,
                                                      float* __restrict__ C, int M, int N, int K, int bx, int by) {
@@ -167,7 +170,7 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
   constexpr int NHI = PIECES - PW_LO * NW;     // (0 when it divides evenly)
   constexpr int SLAB = PIECES * 1024;          // ring of (A 64x128 B | W BNx128 B)
   static_assert(NT_NST * SLAB == nt_lds_bytes<WN, NT_NST, BM>(), "LDS size");
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = HALVES == 1 ? threadIdx.x >> 6 : (threadIdx.x >> 6) % NW;
   const int l15 = lane & 15, q = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = by * BM, n0 = bx * BN;
@@ -1130,6 +1133,152 @@ __device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __r
   }
 }
 
+// 64x64-tile form of the weight-gradient GEMM for contractions short enough to stay in ONE workgroup (BT = 512, the reference's
+// micro-batch: 32 slabs): four waves (2 x 2) of 32x32 = 2 x 2 MFMA tiles, slabs of 16 contraction rows (2 x 4 KB) through an
+// NST-deep LDS-DMA ring.  With S == 1 the workgroup holds the FINAL gradient tile: it is written (or added, `accumulate`: the
+// second micro-step of an accumulation window) straight into the gradient bucket, the tile-column-0 workgroups emit the final
+// bias gradient from the fragments they read anyway, and every workgroup leaves the sum of squares of what it wrote in
+// sq_partial[blockIdx] - no partial planes, no reduction launch, no separate norm pass.  With S > 1 it behaves like the 128x128
+// form (plane s of Cp / cpart, reduced later).
+// LDS: row m of a slab = 64 floats (256 B = all 64 banks), so the two 16-lane groups a ds_read_b64 serves per cycle (rows m, m+1)
+// would hit the same banks: the DMA stores the 128-byte halves of odd rows swapped, the reads undo it.
+template <int NST, int KG>
+__device__ __forceinline__ void gemm_f32_tn64_body(char* lds, const float* __restrict__ dY, const float* __restrict__ X,
+                                                   float* __restrict__ Cp, float* __restrict__ cpart, int cstride,
+                                                   float* __restrict__ sq_partial, int accumulate, int Mrows, int NI, int NJ,
+                                                   int chunk, int bj, int bi, int s, int wg_index) {
+  // KG = 2: 8 waves; waves 4..7 (K-group 1) take rows 16..31 of every 32-row step and their accumulators are added to K-group 0's
+  // through LDS at the end (fixed order): twice the waves per CU for the same tile count, half the dependent chain
+  constexpr int STEP = TN_ROWS * KG, SLAB = 8192 * KG;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int kg = wid >> 2, w4 = wid & 3;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wi = w4 >> 1, wj = w4 & 1;
+  const int i0 = bi * 64, j0 = bj * 64;
+  const int mb = s * chunk, me = min(Mrows, mb + chunk);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x2 csum = {0.f, 0.f};
+  const bool want_cs = cpart != nullptr && bj == 0 && wj == 0;   // wave-uniform
+  const int nst = me > mb ? (me - mb + STEP - 1) / STEP : 0;
+  const int rlast = me > mb ? me - 1 : mb;
+  // DMA: wave w moves rows 4w..4w+3 of the step, both operands (one 1 KB piece each); lane (r4, chunk) fetches the 16 bytes whose LDS
+  // place is row r4, chunk `chunk`, i.e. source half (chunk >> 3) ^ (r4 & 1)
+  const int r4 = lane >> 4, ch = lane & 15;
+  const int scol = ((((ch >> 3) ^ (r4 & 1)) << 5) + ((ch & 7) << 2));
+  auto stage = [&](int t) {
+    char* buf = lds + (t % NST) * SLAB + kg * 8192;
+    int r = mb + t * STEP + wid * 4 + r4;
+    r = r < rlast ? r : rlast;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + (size_t)r * NI + i0 + scol),
+                                     (__attribute__((address_space(3))) void*)(buf + w4 * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)r * NJ + j0 + scol),
+                                     (__attribute__((address_space(3))) void*)(buf + 4096 + w4 * 1024), 16, 0, 0);
+  };
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nst) stage(t);
+  // rows m = 4 ks + q: m & 1 = q & 1
+  const int offA = kg * 8192 + ((wi ^ (q & 1)) << 7) + l15 * 8, offB = kg * 8192 + 4096 + ((wj ^ (q & 1)) << 7) + l15 * 8;
+  for (int t = 0; t < nst; ++t) {
+    const int ahead = min(NST - 2, nst - 1 - t);   // newer steps of this wave (2 DMA instructions each) that may stay in flight
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // step t visible to all waves; everyone is done with step t-1 -> its slot is free
+    if (t + NST - 1 < nst) stage(t + NST - 1);
+    const char* cur = lds + (t % NST) * SLAB;
+#pragma unroll
+    for (int ks = 0; ks < TN_ROWS / 4; ++ks) {
+      const int m = ks * 4 + q;
+      const float keep = (mb + t * STEP + kg * TN_ROWS + m < me) ? 1.f : 0.f;
+      const f32x2 a = *reinterpret_cast<const f32x2*>(cur + offA + m * 256) * keep;
+      const f32x2 b = *reinterpret_cast<const f32x2*>(cur + offB + m * 256);
+      if (want_cs) csum += a;
+#pragma unroll
+      for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ca], b[cb], acc[ca][cb], 0, 0, 0);
+    }
+  }
+  if (KG == 2) {   // K-group 1 -> LDS -> added by K-group 0 (18 floats per lane: 16 accumulators + 2 column sums)
+    float* red = reinterpret_cast<float*>(lds);
+    __syncthreads();   // the ring is no longer read
+    if (kg == 1) {
+#pragma unroll
+      for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((w4 * 18) + (ca * 2 + cb) * 4 + r) * 64 + lane] = acc[ca][cb][r];
+      red[(w4 * 18 + 16) * 64 + lane] = csum[0];
+      red[(w4 * 18 + 17) * 64 + lane] = csum[1];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ca][cb][r] += red[((w4 * 18) + (ca * 2 + cb) * 4 + r) * 64 + lane];
+      csum[0] += red[(w4 * 18 + 16) * 64 + lane];
+      csum[1] += red[(w4 * 18 + 17) * 64 + lane];
+    }
+  }
+  float sq = 0.f;
+  if (kg == 0) {
+    float* cp = Cp + (size_t)s * NI * NJ;
+#pragma unroll
+    for (int ca = 0; ca < 2; ++ca)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi * 32 + 2 * (q * 4 + r) + ca;
+        float* dst = cp + (size_t)i * NJ + j0 + wj * 32 + 2 * l15;
+        f32x2 v = {acc[ca][0][r], acc[ca][1][r]};
+        if (accumulate) v += *reinterpret_cast<const f32x2*>(dst);
+        *reinterpret_cast<f32x2*>(dst) = v;
+        sq += v[0] * v[0] + v[1] * v[1];
+      }
+    if (want_cs) {   // rows m = 4*ks + q were summed per lane: add the four q groups (fixed order -> deterministic)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float v = csum[c];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        csum[c] = v;
+      }
+      if (q == 0) {
+        float* dst = cpart + (size_t)s * cstride + i0 + wi * 32 + 2 * l15;
+        f32x2 v = csum;
+        if (accumulate) v += *reinterpret_cast<const f32x2*>(dst);
+        *reinterpret_cast<f32x2*>(dst) = v;
+        sq += v[0] * v[0] + v[1] * v[1];
+      }
+    }
+  }
+  if (sq_partial) {   // (uniform) one partial per workgroup, fixed order inside: deterministic
+    float* red = reinterpret_cast<float*>(lds) + 4 * 18 * 64;   // (behind the K-group exchange area)
+    __syncthreads();
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) sq_partial[wg_index] = sq;
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_f32_tn64_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                            float* __restrict__ Cp, float* __restrict__ cpart, int cstride,
+                                                            float* __restrict__ sq_partial, int accumulate, int Mrows, int NI,
+                                                            int NJ, int chunk) {
+  __shared__ __attribute__((aligned(16))) char lds[3 * 16384];
+  const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  gemm_f32_tn64_body<3, 2>(lds, dY, X, Cp, cpart, cstride, sq_partial, accumulate, Mrows, NI, NJ, chunk, blockIdx.x, blockIdx.y,
+                           blockIdx.z, wg);
+}
+
 // (3-deep ring here: 48 KB and <= 168 registers let three workgroups share a CU, so the 108 x S tiles of the q/k/v weight
 // gradient - 756 for BT = 2048 - are resident at once instead of leaving a half-empty second round)
 __global__ __launch_bounds__(256, 3) void gemm_f32_tn_lds_kernel(const float* __restrict__ dY, const float* __restrict__ X,
@@ -1165,21 +1314,29 @@ __global__ __launch_bounds__(512, 2) void dgrad_wgrad_kernel(const float* __rest
 // Small-M form of the launch above (BT = 512: the 64x96 data-gradient tiling has 64 workgroups): 256-thread workgroups, the data
 // gradient in 32x32 tiles (gemm_f32_nt_lds_body<.., WN 1, NWM 2, ring 3, MI 1>), the weight-gradient tiles as four waves of 64x64.
 template <int EPI>
-__global__ __launch_bounds__(256, 3) void dgrad_wgrad_small_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                                  const float* __restrict__ R, float* __restrict__ C, int M,
-                                                                  int N, int K, int n_nt,
-                                                                  const float* __restrict__ dY, const float* __restrict__ X,
-                                                                  float* __restrict__ Cp, float* __restrict__ cpart, int cstride,
-                                                                  int NI, int NJ, int chunk) {
-  __shared__ __attribute__((aligned(16))) char lds[3 * 16384];
-  static_assert(nt_lds_bytes<1, 3, 32>() <= 3 * 16384, "LDS");
+__global__ __launch_bounds__(512) void dgrad_wgrad_small_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                               const float* __restrict__ R, float* __restrict__ C, int M,
+                                                               int N, int K, int n_nt, int n_tiles,
+                                                               const float* __restrict__ dY, const float* __restrict__ X,
+                                                               float* __restrict__ Cp, float* __restrict__ cpart, int cstride,
+                                                               int NI, int NJ, int chunk, int t64, float* __restrict__ sq_partial,
+                                                               int accumulate) {
+  constexpr int LDS = TN_NST * 16384 > 3 * 16384 ? TN_NST * 16384 : 3 * 16384;
+  __shared__ __attribute__((aligned(16))) char lds[LDS];
+  static_assert(2 * nt_lds_bytes<1, 3, 32>() <= LDS, "LDS");
   const int b = blockIdx.x;
-  if (b < n_nt) {
-    const int nx = N / 32;
-    gemm_f32_nt_lds_body<EPI, 1, 2, 3, 0, 1>(lds, A, W, nullptr, R, C, M, N, K, b % nx, b / nx);
+  if (b < n_nt) {   // two 32x32 data-gradient tiles per workgroup (the last one may repeat a tile: same values written twice)
+    const int half = threadIdx.x >> 8, nx = N / 32;
+    const int tile = min(2 * b + half, n_tiles - 1);
+    gemm_f32_nt_lds_body<EPI, 1, 2, 3, 0, 1, 2>(lds + half * nt_lds_bytes<1, 3, 32>(), A, W, nullptr, R, C, M, N, K, tile % nx,
+                                                tile / nx);
+  } else if (t64) {   // 64x64 tiles, whole contraction per workgroup (or `chunk` rows of it): see gemm_f32_tn64_body
+    const int t = b - n_nt, tj = NJ >> 6, ti = NI >> 6;
+    gemm_f32_tn64_body<3, 2>(lds, dY, X, Cp, cpart, cstride, sq_partial, accumulate, M, NI, NJ, chunk, t % tj, (t / tj) % ti,
+                             t / (tj * ti), t);
   } else {
     const int t = b - n_nt, tj = NJ >> 7, ti = NI >> 7;
-    gemm_f32_tn_lds_body<4, 3>(lds, dY, X, Cp, cpart, cstride, M, NI, NJ, chunk, t % tj, (t / tj) % ti, t / (tj * ti));
+    gemm_f32_tn_lds_body<8, TN_NST>(lds, dY, X, Cp, cpart, cstride, M, NI, NJ, chunk, t % tj, (t / tj) % ti, t / (tj * ti));
   }
 }
 
@@ -1286,7 +1443,8 @@ struct RedSegs {
 };
 // norm_partial != nullptr: block b also writes the sum of squares of the values it produced to norm_partial[b] (the
 // optimiser's gradient norm without a second pass over the bucket; fixed grid -> fixed order -> deterministic).
-__global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L, float* __restrict__ norm_partial) {   // every n is a multiple of 4 (D % 64 == 0)
+// accumulate: the sums are ADDED to what `out` holds (second.. micro-step of a gradient-accumulation window).
+__global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L, float* __restrict__ norm_partial, int accumulate) {   // every n is a multiple of 4 (D % 64 == 0)
   __shared__ float red[32];
   float sq = 0.f;
   const unsigned long long total4 = L.end[L.count - 1] >> 2;
@@ -1301,6 +1459,7 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(RedSegs L, float* 
     const int S = L.S[g];
     const size_t stride = L.n[g];
     for (int s = 0; s < S; ++s) a += *reinterpret_cast<const f32x4*>(p + (size_t)s * stride);
+    if (accumulate) a += *reinterpret_cast<const f32x4*>(L.out[g] + e);   // (the planes first: out + this gradient, one rounding)
     *reinterpret_cast<f32x4*>(L.out[g] + e) = a;
     sq += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
   }
@@ -1470,8 +1629,20 @@ extern "C" int tspo_selector_forward_ex(const tspo_selector_weights* w, const fl
 
 namespace {
 // cpart != nullptr: the LDS kernel also writes this split's bias-gradient partials; returns through *fused whether it did
+// `fin` (64x64 tiles, the whole contraction in one workgroup: the kernel writes the FINAL gradient): where it goes and whether it is added
+struct FinalGrad {
+  float* w = nullptr;      // != nullptr: final mode; weight gradient [NI][NJ]
+  float* b = nullptr;      // bias gradient [NI]
+  float* sq = nullptr;     // one sum of squares per workgroup (or nullptr)
+  int accumulate = 0;
+};
 int weight_grad(const float* dY, const float* X, float* part, float* cpart, int cstride, int BT, int NI, int NJ,
-                const SelWs& s, hipStream_t st, bool split) {
+                const SelWs& s, hipStream_t st, bool split, const FinalGrad& fin = FinalGrad()) {
+  if (fin.w) {
+    hipLaunchKernelGGL(gemm_f32_tn64_kernel, dim3(NJ / 64, NI / 64, 1), dim3(512), 0, st, dY, X, fin.w, fin.b, 0, fin.sq,
+                       fin.accumulate, BT, NI, NJ, (BT + 3) / 4 * 4);
+    return tspo::check_launch("selector weight_grad (64x64, final)");
+  }
   const int chunk = ((BT + s.S - 1) / s.S + 3) / 4 * 4;
   dim3 grid((NJ + 127) / 128, (NI + 127) / 128, s.S);
   if (split && NI % 128 == 0 && NJ % 128 == 0)
@@ -1487,13 +1658,17 @@ int weight_grad(const float* dY, const float* X, float* part, float* cpart, int 
 template <int EPI>
 int dgrad_with_wgrad(const float* dY, const float* Wt, const float* R, float* dX, int BT, int N, int K, const float* dYw,
                      const float* Xw, float* part, float* cpart, int cstride, int NI, int NJ, const SelWs& s,
-                     hipStream_t st) {
+                     hipStream_t st, const FinalGrad& fin = FinalGrad()) {
   const int chunk = ((BT + s.S - 1) / s.S + 3) / 4 * 4;
   const int n_nt = (N / 96) * ((BT + 63) / 64), n_tn = (NI / 128) * (NJ / 128) * s.S;
   if (n_nt < 256 && N % 32 == 0) {   // small-M form (BT = 512: 28 -> 20.5 us per launch)
-    const int n_nt_s = (N / 32) * ((BT + 31) / 32);
-    hipLaunchKernelGGL((dgrad_wgrad_small_kernel<EPI>), dim3(n_nt_s + n_tn), dim3(256), 0, st, dY, Wt, R, dX, BT, N, K, n_nt_s, dYw,
-                       Xw, part, cpart, cstride, NI, NJ, chunk);
+    const int n_tiles = (N / 32) * ((BT + 31) / 32), n_nt_s = (n_tiles + 1) / 2;
+    if (fin.w)
+      hipLaunchKernelGGL((dgrad_wgrad_small_kernel<EPI>), dim3(n_nt_s + (NI / 64) * (NJ / 64)), dim3(512), 0, st, dY, Wt, R, dX, BT, N,
+                         K, n_nt_s, n_tiles, dYw, Xw, fin.w, fin.b, 0, NI, NJ, (BT + 3) / 4 * 4, 1, fin.sq, fin.accumulate);
+    else
+      hipLaunchKernelGGL((dgrad_wgrad_small_kernel<EPI>), dim3(n_nt_s + n_tn), dim3(512), 0, st, dY, Wt, R, dX, BT, N, K, n_nt_s,
+                         n_tiles, dYw, Xw, part, cpart, cstride, NI, NJ, chunk, 0, (float*)nullptr, 0);
     return tspo::check_launch("selector dgrad+wgrad");
   }
   hipLaunchKernelGGL((dgrad_wgrad_kernel<EPI>), dim3(n_nt + n_tn), dim3(512), 0, st, dY, Wt, R, dX, BT, N, K, n_nt, dYw, Xw,
@@ -1508,7 +1683,8 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
                                   tspo_stream_t stream, int flags, const PgIn* pg = nullptr, float* norm_partials = nullptr,
                                   int* n_partials = nullptr) {
   const bool split = (flags & TSPO_SEL_BF16X3) != 0;
-  TSPO_REQUIRE((flags & ~TSPO_SEL_BF16X3) == 0, "selector_backward: unknown flags 0x%x", flags);
+  const int accum = (flags & TSPO_SEL_ACCUMULATE) ? 1 : 0;
+  TSPO_REQUIRE((flags & ~(TSPO_SEL_BF16X3 | TSPO_SEL_ACCUMULATE)) == 0, "selector_backward: unknown flags 0x%x", flags);
   TSPO_REQUIRE(w && img && txt && (dscores || pg) && g && workspace, "selector_backward: null pointer");
   TSPO_REQUIRE(g->wqkv && g->bqkv && g->w1 && g->b1 && g->w2 && g->b2, "selector_backward: null grad pointer");
   if (int e = check_dims("selector_backward", B, T, D, H, M, window)) return e;
@@ -1533,13 +1709,23 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
   // the two DxD weight gradients shares a launch with the data-gradient GEMM that does not depend on it
   const bool fused = !split && D % 128 == 0 && D % 96 == 0;
   const int cstride = 5 * D;
+  // short contractions (the small-M forms: BT = 512, the reference's micro-batch): 64x64 weight-gradient tiles that hold the whole
+  // contraction write the FINAL gradients (and their sums of squares) - no partial planes, no reduction launch
+  const int t64_tiles = (D / 64) * (D / 64);
+  const bool t64 = fused && (D / 96) * ((BT + 63) / 64) < 256 && (!norm_partials || 5 * t64_tiles <= 2048);
+  FinalGrad f2, f1, fq;
+  if (t64) {
+    f2.w = g->w2; f2.b = g->b2; f2.sq = norm_partials; f2.accumulate = accum;
+    f1.w = g->w1; f1.b = g->b1; f1.sq = norm_partials ? norm_partials + t64_tiles : nullptr; f1.accumulate = accum;
+    fq.w = g->wqkv; fq.b = g->bqkv; fq.sq = norm_partials ? norm_partials + 2 * t64_tiles : nullptr; fq.accumulate = accum;
+  }
   if (fused) {
     // mlp.2 data gradient (dh1) || mlp.2 weight gradient (dh2^T h1)
     if (int e = dgrad_with_wgrad<EPI_MASK>(s.dh2, s.w2t, s.h1, s.dh1, BT, D, D, s.dh2, s.h1, part_w2, s.cpart, cstride, D, D, s,
-                                           st)) return e;
+                                           st, f2)) return e;
     // mlp.0 data gradient (dctx) || mlp.0 weight gradient (dh1^T ctx)
     if (int e = dgrad_with_wgrad<EPI_NONE>(s.dh1, s.w1t, nullptr, s.dctx, BT, D, D, s.dh1, s.ctx, part_w1, s.cpart + D, cstride,
-                                           D, D, s, st)) return e;
+                                           D, D, s, st, f1)) return e;
   } else {
     // mlp.2
     if (int e = weight_grad(s.dh2, s.h1, part_w2, nullptr, 0, BT, D, D, s, st, split)) return e;
@@ -1558,8 +1744,13 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
     hipLaunchKernelGGL(band_attn_bwd_kv_kernel, dim3(pb), dim3(256), 0, st, s.qkv, s.P, s.dS, s.dctx, s.dqkv, B, T, D, H,
                        window);
   // q/k/v projections
-  if (int e = weight_grad(s.dqkv, s.xpe, part_qkv, fused ? s.cpart + 2 * D : nullptr, cstride, BT, 3 * D, D, s, st, split))
+  if (int e = weight_grad(s.dqkv, s.xpe, part_qkv, fused ? s.cpart + 2 * D : nullptr, cstride, BT, 3 * D, D, s, st, split, fq))
     return e;
+  if (t64) {   // every gradient is final
+    if (norm_partials && n_partials) *n_partials = 5 * t64_tiles;
+    (void)img;
+    return tspo::check_launch("selector_backward");
+  }
   // bias grads: column sums of dh2 | dh1 | dqkv (fused above, or CS row slabs here), then every split reduction
   // (3 weights + 3 biases) in one launch
   const int bias_planes = fused ? s.S : s.CS;
@@ -1589,7 +1780,7 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
     if (nb > 2048) nb = 2048;
     if (n_partials) *n_partials = nb;
   }
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L, norm_partials);
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(nb), dim3(256), 0, st, L, norm_partials, accum);
   (void)img;
   return tspo::check_launch("selector_backward");
 }

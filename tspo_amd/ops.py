@@ -198,14 +198,16 @@ def selector_workspace(B, T, D, H, M, window, device) -> torch.Tensor:
     return torch.empty((n,), dtype=torch.uint8, device=device)
 
 
-SEL_BF16X3 = 1   # include/tspo_hip.h: TSPO_SEL_BF16X3
+SEL_BF16X3 = 1       # include/tspo_hip.h: TSPO_SEL_BF16X3
+SEL_ACCUMULATE = 2   # include/tspo_hip.h: TSPO_SEL_ACCUMULATE (backward calls: add to the gradient buffers)
 
 
-def _sel_flags(precision: str) -> int:
+def _sel_flags(precision: str, accumulate: bool = False) -> int:
+    acc = SEL_ACCUMULATE if accumulate else 0
     if precision == "fp32":
-        return 0
+        return acc
     if precision == "bf16x3":
-        return SEL_BF16X3
+        return SEL_BF16X3 | acc
     raise ValueError(f"selector precision must be 'fp32' or 'bf16x3', got {precision!r}")
 
 
@@ -233,8 +235,9 @@ def selector_forward(flat: torch.Tensor, img: torch.Tensor, txt: torch.Tensor, c
 
 
 def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dscores, H, window, tau, ws,
-                      precision: str = "fp32"):
-    """Writes the gradient of every trainable tensor into `flat_grad` (same layout as `flat`)."""
+                      precision: str = "fp32", accumulate: bool = False):
+    """Writes the gradient of every trainable tensor into `flat_grad` (same layout as `flat`); accumulate=True ADDS it to what
+    `flat_grad` holds (gradient accumulation without a scratch bucket)."""
     _need_gpu(flat, flat_grad, img, txt, dscores, ws)
     x, e, d = _f32c(img), _f32c(txt), _f32c(dscores)
     B, T, D = x.shape
@@ -242,16 +245,18 @@ def selector_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, dsc
     w = _sel_structs(flat, D, _lib.SelectorWeights)
     g = _sel_structs(flat_grad, D, _lib.SelectorGrads)
     check(_lib.lib().tspo_selector_backward_ex(C.byref(w), _ptr(x), _ptr(e), _ptr(d), B, T, D, H, M, int(window), float(tau),
-                                               C.byref(g), _ptr(ws), ws.numel(), _stream(), _sel_flags(precision)),
+                                               C.byref(g), _ptr(ws), ws.numel(), _stream(), _sel_flags(precision, accumulate)),
           "tspo_selector_backward")
 
 
 def policy_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, rewards, logp, idx, H, window, tau, ws,
-                    scale: float = 1.0, eps: float = 1e-4, precision: str = "fp32", norm_partials: Optional[torch.Tensor] = None):
+                    scale: float = 1.0, eps: float = 1e-4, precision: str = "fp32", norm_partials: Optional[torch.Tensor] = None,
+                    accumulate: bool = False):
     """grpo_pg_grad + selector_backward with one launch less (the score-gradient kernel derives dL/dscores from the
     rollouts itself): -> (adv [B,G], loss [B]); gradients go to `flat_grad` (equal to the two-call form to rounding).
     norm_partials (f32 [>=2048]): the backward's last kernel also leaves the gradient's partial sums of squares there
-    and the call returns (adv, loss, n_partials) - feed them to adamw_clip_step(norm_partials=...) (one launch)."""
+    and the call returns (adv, loss, n_partials) - feed them to adamw_clip_step(norm_partials=...) (one launch).
+    accumulate=True ADDS the gradients to `flat_grad` (second.. micro-step of an accumulation window)."""
     _need_gpu(flat, flat_grad, img, txt, rewards, logp, idx, ws)
     x, e, r, lp = _f32c(img), _f32c(txt), _f32c(rewards), _f32c(logp)
     ix = idx.to(torch.int64).contiguous()
@@ -272,12 +277,12 @@ def policy_backward(flat: torch.Tensor, flat_grad: torch.Tensor, img, txt, rewar
         npart = C.c_int(0)
         check(_lib.lib().tspo_policy_backward_ex(C.byref(w), _ptr(x), _ptr(e), _ptr(r), _ptr(lp), _ptr(ix), B, T, D, H, M,
                                                  int(window), float(tau), G, k, float(eps), float(scale), C.byref(g), _ptr(adv),
-                                                 _ptr(loss), _ptr(ws), ws.numel(), _stream(), _sel_flags(precision),
+                                                 _ptr(loss), _ptr(ws), ws.numel(), _stream(), _sel_flags(precision, accumulate),
                                                  _ptr(norm_partials), C.byref(npart)), "tspo_policy_backward_ex")
         return adv, loss, int(npart.value)
     check(_lib.lib().tspo_policy_backward(C.byref(w), _ptr(x), _ptr(e), _ptr(r), _ptr(lp), _ptr(ix), B, T, D, H, M, int(window),
                                           float(tau), G, k, float(eps), float(scale), C.byref(g), _ptr(adv), _ptr(loss), _ptr(ws),
-                                          ws.numel(), _stream(), _sel_flags(precision)), "tspo_policy_backward")
+                                          ws.numel(), _stream(), _sel_flags(precision, accumulate)), "tspo_policy_backward")
     return adv, loss
 
 

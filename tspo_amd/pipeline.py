@@ -118,7 +118,6 @@ class PolicyTrainer:
         self._rollouts = 0                      # rollout() calls so far: Philox offset (fresh noise for every call)
         self._param_version = 0                 # bumped by optimizer_step(): a context from before it is stale
         self._ws_pool = []                      # selector workspaces returned by consumed contexts
-        self._gmicro = None                     # scratch bucket of the 2nd.. micro-step's gradient
         self._norm_out = torch.empty((2,), dtype=torch.float32, device=flat.device)
         self._norm_ws = torch.empty((2048,), dtype=torch.uint8, device=flat.device)
         self._norm_part = torch.empty((2048,), dtype=torch.float32, device=flat.device)
@@ -187,12 +186,9 @@ class PolicyTrainer:
             # the device (membership - all the policy gradient uses - does not depend on the order; no host sync)
             idx = torch.sort(idx, dim=-1).values
         B = feats.shape[0]
-        if self._micro == 0:
-            target = self.grad
-        else:
-            if self._gmicro is None:
-                self._gmicro = torch.empty_like(self.grad)
-            target = self._gmicro
+        # the second.. micro-step ADDS its gradient into the bucket inside the backward's own kernels (TSPO_SEL_ACCUMULATE): no
+        # scratch bucket, no add pass
+        target, acc = self.grad, self._micro > 0
         scale = 1.0 / (B * self.grad_accum_steps)
         self._norm_np = 0
         # single rank, no accumulation, default exchange: nothing touches the bucket between this backward and AdamW, so the
@@ -206,13 +202,11 @@ class PolicyTrainer:
             self._norm_grad_version = self.grad._version
         elif idx.shape[1] <= 64:    # advantage -> dL/dscores inside the backward's first kernel (one launch less)
             adv, loss = ops.policy_backward(self.flat, target, feats, txt, rewards, logp, idx, self.heads, self.window, ctx.tau,
-                                            ctx.ws, scale=scale, precision=self.gemm_precision)
+                                            ctx.ws, scale=scale, precision=self.gemm_precision, accumulate=acc)
         else:
             adv, dlog, loss = ops.grpo_pg_grad(rewards, logp, idx, scale=scale)
             ops.selector_backward(self.flat, target, feats, txt, dlog, self.heads, self.window, ctx.tau, ctx.ws,
-                                  precision=self.gemm_precision)
-        if target is not self.grad:
-            self.grad[: self.n_train].add_(target[: self.n_train])
+                                  precision=self.gemm_precision, accumulate=acc)
         self._micro += 1
         ctx.consumed = True
         self._ws_pool.append(ctx.ws)
