@@ -1065,6 +1065,10 @@ __device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __r
   const int nst = me > mb ? (me - mb + TN_ROWS - 1) / TN_ROWS : 0;
   const int rlast = me > mb ? me - 1 : mb;
   const int prow = lane >> 5, pcol = (lane & 31) << 2;
+  // NW = 8 reads its X fragments with ds_read_b64 (two 16-lane groups = rows m, m+1 per cycle, 512 B apart = the same banks):
+  // the DMA stores the 128-byte segments of odd rows pairwise swapped, the reads undo it (dgrad_wgrad_kernel: 10.8 % of LDS cycles
+  // were bank conflicts before, profiles/r4_h_policy_sq_counters.txt)
+  const int pcolB = NW == 8 ? ((((lane & 31) >> 3) ^ prow) << 5) + ((lane & 7) << 2) : pcol;
   auto stage = [&](int t) {   // wave wid moves rows 2*PW*wid .. 2*PW*wid + 2*PW-1 of both slabs
     char* buf = lds + (t % NST) * 16384;
 #pragma unroll
@@ -1074,14 +1078,15 @@ __device__ __forceinline__ void gemm_f32_tn_lds_body(char* lds, const float* __r
       r = r < rlast ? r : rlast;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + (size_t)r * NI + i0 + pcol),
                                        (__attribute__((address_space(3))) void*)(buf + (wid * PW + p) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)r * NJ + j0 + pcol),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)r * NJ + j0 + pcolB),
                                        (__attribute__((address_space(3))) void*)(buf + 8192 + (wid * PW + p) * 1024), 16, 0, 0);
     }
   };
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nst) stage(t);
-  const int offA = (wi * 64 + 4 * l15) * 4, offB = 8192 + (wj * 16 * CB + CB * l15) * 4;
+  // (rows m = 4 ks + q: m & 1 = q & 1; slab rows rr = 2 * piece + prow: rr & 1 = prow)
+  const int offA = (wi * 64 + 4 * l15) * 4, offB = 8192 + ((NW == 8 ? (wj ^ (q & 1)) : wj) * 16 * CB + CB * l15) * 4;
   for (int t = 0; t < nst; ++t) {
     // slabs t+1, t+2 (2*PW DMA instructions each per wave) may stay in flight
     const int ahead = min(NST - 2, nst - 1 - t);
