@@ -4,5 +4,6 @@ timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $OUT/pytest_gp
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > $OUT/smoke.log
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 900 python bench.py --frames 4096 --rollout-cfg 1,4096,16,16 --no-cpu-baseline --no-pruned --no-720p > $OUT/bench_T4096.json 2> $OUT/bench_T4096.err
-bash tools/prof_policy.sh 50 > $OUT/policy_trace.txt 2>&1
+bash tools/prof_policy.sh 50 fp32 > $OUT/policy_trace.txt 2>&1
 cat $OUT/pytest_gpu.log $OUT/smoke.log; tail -3 $OUT/bench.err
+bash tools/prof_policy.sh 50 fp32 dp > $OUT/policy_trace_dp.txt 2>&1
