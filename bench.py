@@ -19,6 +19,7 @@ import json
 import os
 import sys
 import time
+import threading
 
 import torch
 
@@ -303,21 +304,7 @@ def comm_probe(backend: str, world: int, dev, n_bucket: int) -> dict:
             "bucket_bytes": 4 * n_bucket, "allreduce_us": None}
 
     def time_allreduce(group, reps=20):
-        bucket = torch.zeros(n_bucket + 8, dtype=torch.float32, device=dev)
-        for _ in range(3):
-            tdist.allreduce_bucket_(bucket, n_bucket, group)
-        torch.cuda.synchronize()
-        if dist.get_world_size(group) > 1:
-            dist.barrier(group)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            tdist.allreduce_bucket_(bucket, n_bucket, group)
-        torch.cuda.synchronize()
-        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        if dist.get_world_size(group) > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        return t.item()
+        return _time_allreduce(backend, dev, n_bucket, group, reps)
 
     try:
         info["world"] = dist.get_world_size()
@@ -341,25 +328,52 @@ def comm_probe(backend: str, world: int, dev, n_bucket: int) -> dict:
                 info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:
                 pass
-            if info["world"] > 1:       # Ring vs Tree: NCCL_ALGO is read when a communicator is created
-                by_algo, keep = {}, os.environ.get("NCCL_ALGO")
-                for algo in ("Ring", "Tree"):
-                    try:
-                        os.environ["NCCL_ALGO"] = algo
-                        grp = dist.new_group(backend="nccl")
-                        by_algo[algo] = round(time_allreduce(grp), 1)
-                    except Exception as e:
-                        by_algo[algo] = f"{type(e).__name__}: {e}"[:120]
-                if keep is None:
-                    os.environ.pop("NCCL_ALGO", None)
-                else:
-                    os.environ["NCCL_ALGO"] = keep
-                info["allreduce_us_by_algo"] = by_algo
+            # (Ring vs Tree needs extra communicators: comm_algo_probe, run LAST and under a watchdog - never before a timed region)
             if os.environ.get("NCCL_DEBUG_FILE"):
                 info["rccl_debug"] = rccl_debug_summary(os.environ["NCCL_DEBUG_FILE"])
     except Exception as e:
         info["error"] = f"{type(e).__name__}: {e}"[:300]
     return info
+
+
+def _time_allreduce(backend: str, dev, n_bucket: int, group, reps: int = 20) -> float:
+    """us per all-reduce of the gradient bucket on `group` (max over ranks)."""
+    import torch.distributed as dist
+    from tspo_amd import dist as tdist
+    bucket = torch.zeros(n_bucket + 8, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        tdist.allreduce_bucket_(bucket, n_bucket, group)
+    torch.cuda.synchronize()
+    if dist.get_world_size(group) > 1:
+        dist.barrier(group)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tdist.allreduce_bucket_(bucket, n_bucket, group)
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.item()
+
+
+def comm_algo_probe(dev, n_bucket: int) -> dict:
+    """N > 1, RCCL: the bucket all-reduce on communicators created with NCCL_ALGO=Ring and =Tree (the variable is read when a
+    communicator is created).  Creates extra communicators, so the caller runs it AFTER every timed region and under a watchdog."""
+    import torch.distributed as dist
+    by_algo, keep = {}, os.environ.get("NCCL_ALGO")
+    for algo in ("Ring", "Tree"):
+        try:
+            os.environ["NCCL_ALGO"] = algo
+            grp = dist.new_group(backend="nccl")
+            by_algo[algo] = round(_time_allreduce("nccl", dev, n_bucket, grp), 1)
+        except Exception as e:
+            by_algo[algo] = f"{type(e).__name__}: {e}"[:120]
+    if keep is None:
+        os.environ.pop("NCCL_ALGO", None)
+    else:
+        os.environ["NCCL_ALGO"] = keep
+    return by_algo
 
 
 def one_rank_group(backend: str, dev):
@@ -679,7 +693,37 @@ def main():
             "launcher": "torch.distributed.run" if (world > 1 and not os.environ.get("TSPO_SELF_SPAWNED")) else
                         ("self-spawn" if world > 1 else "single process"),
         }
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
+    # ---- N > 1 on RCCL: Ring vs Tree all-reduce on extra communicators.  LAST, and under a watchdog: if creating them hangs on this
+    #      node, rank 0 still prints the measured line (every number above is already final) and all ranks leave ----
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            try:      # librccl announces itself through C stdio ("Librccl path : ..."), which would otherwise be flushed at exit,
+                import ctypes                      # AFTER the line: push it out now so the JSON line is the last line of stdout
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(line), flush=True)
+
+    if world > 1 and comm is not None and "error" not in comm and a.backend == "nccl" and not a.no_comm_probe:
+        def bail():
+            if rank == 0 and line is not None and isinstance(line.get("comm"), dict):
+                line["comm"]["allreduce_us_by_algo"] = "skipped: the extra communicators did not come up within 120 s"
+            emit()
+            os._exit(0)
+        dist.barrier()            # (rank 0 profiled a little longer: start the clock together)
+        dog = threading.Timer(120.0, bail)
+        dog.daemon = True
+        dog.start()
+        by_algo = comm_algo_probe(dev, ops.trainable_numel(768))
+        dog.cancel()
+        if rank == 0:
+            line["comm"]["allreduce_us_by_algo"] = by_algo
+    emit()
     if world > 1:
         dist.barrier()   # rank 0 is still profiling / printing while the others are done: leave together
         dist.destroy_process_group()
