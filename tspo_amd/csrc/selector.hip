@@ -318,7 +318,9 @@ int launch_gemm_nt_p(const float* A, const float* W, const float* bias, const fl
   // spread the MFMAs over every CU: DxD at BT = 512 26 -> 12-13 us, Dx3D 27 -> 25.5 us (4.5 wave-tiles per SIMD: 32x64 / 32x96 /
   // 64x96 tiles all end at 26-27 us, the CU with one workgroup more sets the time).  Measured and not kept: fragments of slab kt+1
   // read under the MFMAs of slab kt with the DMA three slabs ahead (12.7-13.7 vs 11.9-13.0 us), a 4-deep ring (same).  Same
-  // contraction order per output element as the large form: bitwise the same results.
+  // contraction order per output element as the large form: bitwise the same results.  At BT = 2048 the DxD forwards take 28 us with
+  // ANY of the tilings (64x96, 32x96, 32x64, 32x32: +-0.3 % on the step), and a 64-row problem still takes 9.3-10 us: the floor is the
+  // serial chain of 24 K-steps (barrier, DMA issue, fragment reads, 8 dependent MFMAs: ~800 cycles each), not the tile shape.
   if (K % 32 == 0 && N % 32 == 0 && (long)(N / 96) * mt < 256) {
     hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 1, 2, 3, SPLIT, 1>), dim3(N / 32, (M + 31) / 32), dim3(256), 0, st, A, W, bias, R, C,
                        M, N, K);
