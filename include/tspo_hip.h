@@ -184,6 +184,7 @@ int tspo_selector_backward_ex(const tspo_selector_weights* w, const float* img, 
  * (rewards [B,G], logp [B,T], idx [B,G,k] ascending) - same arithmetic and
  * order as tspo_grpo_pg_grad: adv / loss are bit-identical to the two-call
  * form, gradients agree to rounding (< 1e-6 of their maximum).  G <= 64.  `scale` multiplies dL/dscores (e.g. 1/(B*accum)).
+ * flags: TSPO_SEL_BF16X3 and / or TSPO_SEL_ACCUMULATE (add to the gradient buffers: micro-steps 2.. of an accumulation window).
  * Replaces loss.backward() of tspo_trainer.py:587-609 end to end.           */
 int tspo_policy_backward(const tspo_selector_weights* w, const float* img, const float* txt,
                          const float* rewards, const float* logp, const int64_t* idx,
