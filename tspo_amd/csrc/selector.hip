@@ -151,13 +151,16 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restric
 // Small-M form (BM = 32: NWM = 2, MI = 1, four waves): with BT = 512 rows - one prompt per micro-step, the reference's training
 // configuration - 64-row tiles give 64 (DxD) or 192 (Dx3D) workgroups for 256 CUs and the launch takes one workgroup's 24 K-steps
 // (26-27 us whatever N is); 32-row tiles spread the same MFMAs over 2-4x as many CUs.
-template <int WN, int NT_NST, int BM = 64>
-constexpr int nt_lds_bytes() { return NT_NST * (BM / 8 + 4 * WN) * 1024; }
+template <int WN, int NT_NST, int BM = 64, int SPB = 1>
+constexpr int nt_lds_bytes() { return NT_NST * SPB * (BM / 8 + 4 * WN) * 1024; }
 
 // (body of the kernel: also instantiated inside dgrad_wgrad_kernel, which runs it next to a weight-gradient tile set)
 // HALVES = 2: the workgroup has 2 x NWM*2 waves and runs TWO tiles side by side (waves 0..NW-1 one, NW..2NW-1 the other: the caller
 // passes each half its own lds / bx / by; the K-loops are the same length, so the workgroup-wide barriers line up).
-template <int EPI, int WN, int NWM, int NT_NST, int SPLIT, int MI = 4 / NWM, int HALVES = 1>
+// SPB = 2: TWO 32-deep slabs per ring stage and barrier (K / 32 even).  A K-step of a small tile is ~650 cycles of wait + barrier + DMA
+// issue + fragment-read latency around 256 cycles of dependent MFMAs (cycle-counter probe, round 4): pairing the slabs halves the
+// number of such steps, and the ring (NT_NST stages of two slabs) holds twice as many slabs in flight.  Same contraction order.
+template <int EPI, int WN, int NWM, int NT_NST, int SPLIT, int MI = 4 / NWM, int HALVES = 1, int SPB = 1>
 __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __restrict__ A, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ R,
                                                      float* __restrict__ C, int M, int N, int K, int bx, int by) {
@@ -169,17 +172,20 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
   constexpr int PW_HI = (PIECES + NW - 1) / NW, PW_LO = PIECES / NW;   // first NHI waves move PW_HI pieces, the rest PW_LO
   constexpr int NHI = PIECES - PW_LO * NW;     // (0 when it divides evenly)
   constexpr int SLAB = PIECES * 1024;          // ring of (A 64x128 B | W BNx128 B)
-  static_assert(NT_NST * SLAB == nt_lds_bytes<WN, NT_NST, BM>(), "LDS size");
+  static_assert(NT_NST * SPB * SLAB == nt_lds_bytes<WN, NT_NST, BM, SPB>(), "LDS size");
   const int lane = threadIdx.x & 63, wid = HALVES == 1 ? threadIdx.x >> 6 : (threadIdx.x >> 6) % NW;
   const int l15 = lane & 15, q = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = by * BM, n0 = bx * BN;
-  const int nk = K >> 5;
+  const int nk = (K >> 5) / SPB;            // ring stages (SPB slabs each; the launcher checks divisibility)
   const int rin = lane >> 3, slot = lane & 7;
   const bool hi = NHI == 0 || wid < NHI;
   const int piece0 = hi ? wid * PW_HI : NHI * PW_HI + (wid - NHI) * PW_LO;
   auto stage = [&](int kt, int ring) {
-    char* buf = lds + ring * SLAB;
+#pragma unroll
+    for (int sub = 0; sub < SPB; ++sub) {
+    char* buf = lds + (ring * SPB + sub) * SLAB;
+    const int kslab = kt * SPB + sub;
 #pragma unroll
     for (int p = 0; p < PW_HI; ++p) {
       if (p < PW_LO || hi) {
@@ -192,14 +198,15 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
         } else {
           src = W + (size_t)(n0 + (piece - AP) * 8 + rin) * K;
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + kt * 32 + ((slot ^ rin) << 2)),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + kslab * 32 + ((slot ^ rin) << 2)),
                                          (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
       }
+    }
     }
   };
   // wait until slab kt has landed: the (NT_NST - 2) newer slabs of this wave (PW pieces each) may stay in flight
   auto wait_ahead = [&](int ahead) {
-    const int cnt = ahead * (hi ? PW_HI : PW_LO);
+    const int cnt = ahead * SPB * (hi ? PW_HI : PW_LO);
     switch (cnt) {   // s_waitcnt needs an immediate
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
@@ -230,14 +237,32 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
 #pragma unroll
   for (int t = 0; t < NT_NST - 1; ++t)
     if (t < nk) stage(t, t);
+  // epilogue operands (bias, residual / mask source) are fetched NOW, behind the first slabs' DMAs: loaded in the epilogue they were
+  // first-touch misses on its critical path (probe: 8-10 k of a 64 k-cycle DxD launch at BT = 2048)
+  float bv[WN], rv[MI][WN][4];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = n0 + wn * 16 * WN + 16 * j + l15;
+    bv[j] = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 16 * MI + 16 * i + q * 4 + r;
+        rv[i][j][r] = (EPI == EPI_RESID || EPI == EPI_MASK) ? R[(size_t)(row < M ? row : M - 1) * N + col] : 0.f;
+      }
+  }
   int ring = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // slabs kt+1 .. kt+NT_NST-2 stay in flight across the wait (2-deep ring: everything has landed)
     wait_ahead(min(NT_NST - 2, nk - 1 - kt));
     __builtin_amdgcn_s_barrier();   // slab kt visible to all waves; compute(kt-1) done everywhere -> its slot is free
     if (kt + NT_NST - 1 < nk) stage(kt + NT_NST - 1, ring >= 1 ? ring - 1 : NT_NST - 1);
-    const char* cur = lds + ring * SLAB;
+    const int ring_now = ring;
     ring = ring + 1 == NT_NST ? 0 : ring + 1;
+#pragma unroll
+    for (int sub = 0; sub < SPB; ++sub) {
+    const char* cur = lds + (ring_now * SPB + sub) * SLAB;
     if (SPLIT) {
       // one bf16 MFMA spans the whole 32-deep slab: lane (row l15, q) owns k = 8q..8q+7 = 16-byte chunks 2q, 2q+1
       const int c0 = (((2 * q) ^ sw) << 4), c1 = (((2 * q + 1) ^ sw) << 4);
@@ -279,35 +304,35 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
           for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][st], b[j][st], acc[i][j], 0, 0, 0);
     }
     }
+    }   // sub
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int col = n0 + wn * 16 * WN + 16 * j + l15;
-      const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * 16 * MI + 16 * i + q * 4 + r;
         if (row < M) {
-          float v = acc[i][j][r] + bv;
+          float v = acc[i][j][r] + bv[j];
           const size_t o = (size_t)row * N + col;
           if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-          if (EPI == EPI_RESID) v += R[o];
-          if (EPI == EPI_MASK) v = R[o] > 0.f ? v : 0.f;
+          if (EPI == EPI_RESID) v += rv[i][j][r];
+          if (EPI == EPI_MASK) v = rv[i][j][r] > 0.f ? v : 0.f;
           C[o] = v;
         }
       }
     }
 }
 
-template <int EPI, int WN, int NWM, int NT_NST, int SPLIT, int MI = 4 / NWM>
+template <int EPI, int WN, int NWM, int NT_NST, int SPLIT, int MI = 4 / NWM, int SPB = 1>
 __global__ __launch_bounds__(NWM * 128) void gemm_f32_nt_lds_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ R, float* __restrict__ C,
                                                                     int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) char lds[nt_lds_bytes<WN, NT_NST, 16 * NWM * MI>()];   // the only LDS object
-  gemm_f32_nt_lds_body<EPI, WN, NWM, NT_NST, SPLIT, MI>(lds, A, W, bias, R, C, M, N, K, blockIdx.x, blockIdx.y);
+  __shared__ __attribute__((aligned(16))) char lds[nt_lds_bytes<WN, NT_NST, 16 * NWM * MI, SPB>()];   // the only LDS object
+  gemm_f32_nt_lds_body<EPI, WN, NWM, NT_NST, SPLIT, MI, 1, SPB>(lds, A, W, bias, R, C, M, N, K, blockIdx.x, blockIdx.y);
 }
 
 template <int EPI, int SPLIT>
@@ -322,8 +347,18 @@ int launch_gemm_nt_p(const float* A, const float* W, const float* bias, const fl
   // ANY of the tilings (64x96, 32x96, 32x64, 32x32: +-0.3 % on the step), and a 64-row problem still takes 9.3-10 us: the floor is the
   // serial chain of 24 K-steps (barrier, DMA issue, fragment reads, 8 dependent MFMAs: ~800 cycles each), not the tile shape.
   if (K % 32 == 0 && N % 32 == 0 && (long)(N / 96) * mt < 256) {
-    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 1, 2, 3, SPLIT, 1>), dim3(N / 32, (M + 31) / 32), dim3(256), 0, st, A, W, bias, R, C,
-                       M, N, K);
+    if (K % 64 == 0)   // two slabs per barrier: a 512-row DxD launch 27.1 k -> 23.2 k cycles, a 64-row one 21.4 k -> 16.9 k (probe)
+      hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 1, 2, 3, SPLIT, 1, 2>), dim3(N / 32, (M + 31) / 32), dim3(256), 0, st, A, W, bias, R,
+                         C, M, N, K);
+    else
+      hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 1, 2, 3, SPLIT, 1>), dim3(N / 32, (M + 31) / 32), dim3(256), 0, st, A, W, bias, R,
+                         C, M, N, K);
+    return tspo::check_launch("selector gemm_nt");
+  }
+  if (K % 64 == 0 && N % 96 == 0 && (long)(N / 96) * mt <= 256) {
+    // one workgroup per CU (DxD at BT = 2048): two slabs per barrier, two such stages (80 KB): 64.2 k -> 55.6 k cycles per launch
+    // (probe; with three stages 59.3 k); the epilogue's share 8.0 k -> 4.4 k by fetching its operands before the K-loop
+    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4, 2, SPLIT, 1, 2>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
     return tspo::check_launch("selector gemm_nt");
   }
   // ring depth 3 keeps two workgroups (16 waves) per CU; when the grid holds more than two workgroups per CU a 2-deep
