@@ -513,6 +513,19 @@ def test_selector_small_micro_batch_forms_and_accumulate():
         ops.selector_backward(flat, gsum, img[sl], txt[sl], ds[sl], H, w, tau, ws1, accumulate=True)
     gmax = g4[:n].abs().max().item()
     assert gmax > 0 and (gsum[:n] - g4[:n]).abs().max().item() <= 5e-6 * gmax
+    # the B = 4 forms in split precision (two-slab ring of the DxD launches included) against exact fp32
+    s4x, h4x, ws4x = ops.selector_forward(flat, img, txt, clip, H, w, tau, precision="bf16x3")
+    assert ((s4x - s4).abs().max() / s4.abs().max()).item() < 2e-4 and ((h4x - h4).abs().max() / h4.abs().max()).item() < 5e-5
+    g4x = torch.zeros_like(flat)
+    ops.selector_backward(flat, g4x, img, txt, ds, H, w, tau, ws4x, precision="bf16x3")
+    # (mlp.2 only: upstream of the ReLU a pre-activation within ~1e-5 of zero flips its mask bit between the two precisions, and ONE
+    #  flipped term moves an entry of the mlp.0 / q,k,v gradients - sums of ~BT/2 random-sign terms - by percents: measured 1e-2 of
+    #  the tensor's maximum at this shape with either round's library; not an error of the GEMMs)
+    offs = ops.flat_offsets(D)
+    for pn in ("mlp.2.weight", "mlp.2.bias"):
+        off, shape = offs[pn]
+        a, b = g4[off:off + int(np.prod(shape))], g4x[off:off + int(np.prod(shape))]
+        assert ((a - b).abs().max() / a.abs().max()).item() < 2e-4, pn
     # accumulate adds exactly: once more onto itself
     for (imgs, txts, clips, dss, prec) in ((img[:1], txt[:1], clip[:1], ds[:1], "fp32"), (img, txt, clip, ds, "fp32"),
                                            (img[:1], txt[:1], clip[:1], ds[:1], "bf16x3")):
