@@ -103,7 +103,7 @@ def test_agpr_gemm_code_audit(tmp_path, src, kernel):
                            os.path.join(b.CSRC, src), "-o", str(asm)])
     txt = open(asm).read()
     kernels = re.findall(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)\n\.Lfunc_end" % kernel, txt, flags=re.S | re.M)
-    assert len(kernels) == 8, [k[0] for k in kernels]
+    assert len(kernels) == 9, [k[0] for k in kernels]   # the eight epilogue forms + the head-major q/k/v form (GE_BIAS_LN_HM)
     for name, body in kernels:
         inasm, bad, m0bad = False, [], []
         blocks, cur = [], []

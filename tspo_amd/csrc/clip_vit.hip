@@ -535,8 +535,11 @@ __device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const 
 }
 
 
+// hm: qkv is the head-major image the q/k/v GEMM wrote (GE_BIAS_LN_HM: [3 * heads][M][64]): the item's q, k and v rows are three
+// contiguous 33 KB blocks (row pitch 64) instead of 128-byte pieces of 6 KB rows - same values, the staging loads of a workgroup
+// become one linear stream (measured with the round-4 layout experiment: 11.9 -> 11.1 ms per forward).
 __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int C,
-                                                              float scale) {
+                                                              float scale, int hm) {
   constexpr int S = 257;
   __shared__ __attribute__((aligned(16))) char lds[A4_LDS_BYTES];
   char* Ks = lds;
@@ -551,8 +554,11 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
   const int item = (nwg & 7) == 0 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
   const int h = item % (int)gridDim.x;
   const size_t f = item / (int)gridDim.x;
-  const size_t ld = (size_t)3 * C;
-  const bf16_t* base = qkv + f * S * ld + (size_t)h * 64;
+  const size_t ld = hm ? 64 : (size_t)3 * C;
+  const size_t hm_part = (size_t)gridDim.x * gridDim.y * S * 64;   // one of q | k | v in the head-major image: heads * M * 64
+  const bf16_t* base = hm ? qkv + (((size_t)h * gridDim.y * S + f * S) << 6) : qkv + f * S * ld + (size_t)h * 64;   // q rows
+  const bf16_t* kbase = base + (hm ? hm_part : (size_t)C);
+  const bf16_t* vbase = base + (hm ? 2 * hm_part : (size_t)2 * C);
   bf16x8 qf4[4][2];
   {   // stage K (swizzled 128-byte rows) and V (row-major [32 keys][16 d] sub-tiles): all loads in flight, then the writes
     uint4 kv[9], vv[9];
@@ -561,8 +567,8 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
       const int id = tid + i * 256;
       const int row = id >> 3, c = id & 7;
       const int rc = row < S ? row : S - 1;
-      kv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + C + c * 8);
-      vv[i] = *reinterpret_cast<const uint4*>(base + (size_t)rc * ld + 2 * C + c * 8);
+      kv[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)rc * ld + c * 8);
+      vv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)rc * ld + c * 8);
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -726,11 +732,14 @@ struct Prof {
 // get_image_features pools row 0).  One wave per (frame, head): scores of q_0 against all S keys (lane j owns keys
 // j, j+64, ...), softmax across the wave, then lane d accumulates sum_j p_j V[j][d] with p broadcast through LDS.
 __global__ __launch_bounds__(64) void clip_attn_cls_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
-                                                           int C, float scale) {
+                                                           int C, float scale, int hm) {
   __shared__ float pl[AT_KEYS];
   const int lane = threadIdx.x, h = blockIdx.x;
-  const size_t f = blockIdx.y, ld = (size_t)3 * C;
-  const bf16_t* base = qkv + f * S * ld + (size_t)h * 64;
+  const size_t f = blockIdx.y, ld = hm ? 64 : (size_t)3 * C;
+  const size_t hm_part = (size_t)gridDim.x * gridDim.y * S * 64;   // (see clip_attn257_kernel)
+  const bf16_t* base = hm ? qkv + (((size_t)h * gridDim.y * S + f * S) << 6) : qkv + f * S * ld + (size_t)h * 64;
+  const bf16_t* kbase = base + (hm ? hm_part : (size_t)C);
+  const bf16_t* vbase = base + (hm ? 2 * hm_part : (size_t)2 * C);
   float q[64];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(64) void clip_attn_cls_kernel(const bf16_t* __restr
     const int key = lane + 64 * i;
     float d = -INFINITY;
     if (key < S) {
-      const bf16_t* kr = base + (size_t)key * ld + C;
+      const bf16_t* kr = kbase + (size_t)key * ld;
       d = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -776,7 +785,7 @@ __global__ __launch_bounds__(64) void clip_attn_cls_kernel(const bf16_t* __restr
   sum = wave_sum(sum);
   __syncthreads();
   float o = 0.f;
-  const bf16_t* vb = base + 2 * C + lane;
+  const bf16_t* vb = vbase + lane;
   for (int key = 0; key < S; ++key) o += pl[key] * bf16_to_f32(vb[(size_t)key * ld]);
   o /= sum;
   // bf16 store of this head's 64 outputs of frame f (compact [n_frames, C] layout)
@@ -1039,6 +1048,8 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
     prof.tick(PK_LN);
   }
   bool pooled_done = false;
+  // the folded q/k/v GEMM writes its output head-major for the 257-token attention kernel (GE_BIAS_LN_HM, gemm_bf16.h)
+  const int hm = (fold && S == 257 && c.heads * 64 == C) ? 1 : 0;
   for (int l = 0; l < c.layers; ++l) {
     const tspo_clip_layer& L = w->layers[l];
     TSPO_REQUIRE(L.ln1_g && L.ln1_b && L.wqkv && L.bqkv && L.wo && L.bo && L.ln2_g && L.ln2_b && L.w1 && L.b1 && L.w2 && L.b2,
@@ -1053,7 +1064,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       prof.tick(PK_LN);
       g.A = b.x; g.W = b.wqkv_f; g.bias = b.dq; g.lnc = b.cq; g.rstats = b.stats; g.C = b.qkv;
       g.M = (int)M; g.N = 3 * C; g.K = C; g.P = 1;
-      if (int e = tspo::gemm_bf16(GE_BIAS_LN, g, st)) return e;
+      if (int e = tspo::gemm_bf16(hm ? GE_BIAS_LN_HM : GE_BIAS_LN, g, st)) return e;
     } else {
       if (int e = run_ln(b.x, b.h, L.ln1_g, L.ln1_b, M, C, C, C, c.ln_eps, st)) return e;
       prof.tick(PK_LN);
@@ -1065,7 +1076,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       // Only row 0 of every frame leaves the encoder (post-LN + projection of the class token), so the rest of this
       // block runs on the compact [n_frames, C] class-token rows: attention of q_0, out-proj, LN2, MLP.
       bf16_t* xc = b.h + (size_t)n_frames * C;   // class-token residual rows (b.h is free here); LN2 output goes to b.h
-      hipLaunchKernelGGL(clip_attn_cls_kernel, dim3(c.heads, n_frames), dim3(64), 0, st, b.qkv, b.a, S, C, 0.125f);
+      hipLaunchKernelGGL(clip_attn_cls_kernel, dim3(c.heads, n_frames), dim3(64), 0, st, b.qkv, b.a, S, C, 0.125f, hm);
       if (int e = tspo::check_launch("clip_attn_cls")) return e;
       prof.tick(PK_ATTN);
       hipError_t ce = hipMemcpy2DAsync(xc, (size_t)C * 2, b.x, (size_t)S * C * 2, (size_t)C * 2, n_frames,
@@ -1090,7 +1101,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       pooled_done = true;
       break;
     }
-    if (S == 257) hipLaunchKernelGGL(clip_attn257_kernel, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f);
+    if (S == 257) hipLaunchKernelGGL(clip_attn257_kernel, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, C, 0.125f, hm);
     else hipLaunchKernelGGL(clip_attn_kernel<0>, dim3(c.heads, n_frames), dim3(256), 0, st, b.qkv, b.a, S, C, 0.125f);
     if (int e = tspo::check_launch("clip_attn")) return e;
     prof.tick(PK_ATTN);

@@ -218,6 +218,7 @@ int tspo::gemm_bf16_agpr(int epi, const GemmArgs& g, hipStream_t st) {
     case GE_PATCH: return launch_a7_variant<GE_PATCH>(g, st);
     case GE_BIAS_LN: return launch_a7_variant<GE_BIAS_LN>(g, st);
     case GE_GELU_LN: return launch_a7_variant<GE_GELU_LN>(g, st);
+    case GE_BIAS_LN_HM: return launch_a7_variant<GE_BIAS_LN_HM>(g, st);
     case GE_RESID_ST: return launch_a7_variant<GE_RESID_ST>(g, st);
   }
   return tspo::set_err(TSPO_EINVAL, "gemm_agpr: bad epilogue %d", epi);

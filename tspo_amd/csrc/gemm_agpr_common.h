@@ -77,7 +77,7 @@ __device__ __forceinline__ void agpr_epilogue(const GemmArgs& g, int m0, int n0,
                                               const EpiPre& p0) {
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first v_accvgpr_read
   constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
-  constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
+  constexpr bool LN = epi_is_ln(EPI);
   float2 rst[8];
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) rst[mi] = LN ? g3_epi_rowstat(g, m0 + wm * 128 + mi * 16 + l15) : make_float2(1.f, 0.f);

@@ -8,7 +8,12 @@ typedef uint16_t bf16_t;
 // the epilogue applies the per-row statistics: y = rstd_m * acc - (mu_m * rstd_m) * lnc[n] + bias[n] with lnc[n] = sum_k W'[n,k]
 // and bias = the folded bias (b + W beta).  GE_RESID_ST: GE_RESID that also writes, per row and 64-column slice, the (mean, centred sum
 // of squares) of the bf16 values it stores: spart[m][N/64][2]  (LayerNorm folded into the GEMMs around it).
-enum { GE_BIAS = 0, GE_GELU = 1, GE_RESID = 2, GE_F32 = 3, GE_PATCH = 4, GE_BIAS_LN = 5, GE_GELU_LN = 6, GE_RESID_ST = 7 };
+// GE_BIAS_LN_HM ("head-major"): GE_BIAS_LN whose bf16 output is stored by 64-column blocks, C[N/64][M][64] instead of C[M][N] - the
+// q/k/v projection of the encoder: head h of part p (q, k, v) is block p*heads + h, so the 257 rows of a (frame, head) item are ONE
+// contiguous 33 KB block for the attention kernel instead of 257 pieces of 128 B at a 6 KB pitch.  Same values, no extra arithmetic
+// in the epilogue (block base + m * 64 in place of m * N).  N % 64 == 0.
+enum { GE_BIAS = 0, GE_GELU = 1, GE_RESID = 2, GE_F32 = 3, GE_PATCH = 4, GE_BIAS_LN = 5, GE_GELU_LN = 6, GE_RESID_ST = 7,
+       GE_BIAS_LN_HM = 8 };
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* W; const float* bias; const bf16_t* R; void* C;

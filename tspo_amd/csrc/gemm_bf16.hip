@@ -192,6 +192,7 @@ int tspo::gemm_bf16(int epi, const GemmArgs& g, hipStream_t st) {
   switch (epi) {
     case GE_BIAS_LN: return launch_gemm_ln<GE_BIAS_LN>(g, st);
     case GE_GELU_LN: return launch_gemm_ln<GE_GELU_LN>(g, st);
+    case GE_BIAS_LN_HM: return launch_gemm_ln<GE_BIAS_LN_HM>(g, st);
     case GE_RESID_ST: return launch_gemm_ln<GE_RESID_ST>(g, st);
     case GE_BIAS: return launch_gemm<GE_BIAS>(g, st);
     case GE_GELU: return launch_gemm<GE_GELU>(g, st);

@@ -7,8 +7,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 __host__ __device__ constexpr bool epi_has_bias(int epi) {
-  return epi == GE_BIAS || epi == GE_GELU || epi == GE_RESID || epi == GE_BIAS_LN || epi == GE_GELU_LN || epi == GE_RESID_ST;
+  return epi == GE_BIAS || epi == GE_GELU || epi == GE_RESID || epi == GE_BIAS_LN || epi == GE_GELU_LN || epi == GE_RESID_ST ||
+         epi == GE_BIAS_LN_HM;
 }
+__host__ __device__ constexpr bool epi_is_ln(int epi) { return epi == GE_BIAS_LN || epi == GE_GELU_LN || epi == GE_BIAS_LN_HM; }
 
 #define GT_BM 128
 #define GT_BN 128
@@ -29,7 +31,7 @@ __device__ __forceinline__ float quick_gelu_f(float x) {
 struct EpiCols { f32x4 lc[4]; f32x4 bias[4]; };   // bias[] only for the PRE (register-prefetched) form of g3_epi_row
 template <int EPI>
 __device__ __forceinline__ void g3_epi_cols(const GemmArgs& g, int n0, int wn, int q4, EpiCols& ec) {
-  if (EPI == GE_BIAS_LN || EPI == GE_GELU_LN) {
+  if (epi_is_ln(EPI)) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wn * 64 + ni * 16 + q4 * 4;
@@ -48,7 +50,7 @@ __device__ __forceinline__ float2 g3_epi_rowstat(const GemmArgs& g, int m) {   /
 template <int EPI, bool PRE = false, bool FULL = false>
 __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], const EpiCols& ec, float2 rst, int m, int n0,
                                            int wn, int q4, const float* lbias, const uint2* rpre = nullptr) {
-  constexpr bool LN = EPI == GE_BIAS_LN || EPI == GE_GELU_LN;
+  constexpr bool LN = epi_is_ln(EPI);
   constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
   size_t orow = (size_t)m;
   int prow = 0;
@@ -141,7 +143,9 @@ __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], co
       if (FULL || (m < g.M && n < g.N)) {
         uint4 st;
         st.x = w0[0]; st.y = w1[0]; st.z = w0[1]; st.w = w1[1];
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + orow * g.N + n) = st;
+        // (head-major form: the 64-column slice (n0 >> 6) + wn of the output is its own [M][64] matrix)
+        const size_t o16 = EPI == GE_BIAS_LN_HM ? (((size_t)((n0 >> 6) + wn) * g.M + orow) << 6) + (n & 63) : orow * g.N + n;
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + o16) = st;
       }
     }
   }
