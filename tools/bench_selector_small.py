@@ -55,4 +55,4 @@ def full():
 t_f = timeit(fwd_only)
 t_s = timeit(full)
 hg = hashlib.sha256(tr.grad.cpu().numpy().tobytes()).hexdigest()[:12]
-print(f"B={B} T={T} NT_SMALL={os.environ.get('TSPO_NT_SMALL', '0')} DG={os.environ.get('TSPO_DG_SMALL', '0')} S={os.environ.get('TSPO_S', '-')}: rollout (forward + sampler) {t_f:.1f} us, whole step {t_s:.1f} us  scores {h} grad {hg}")
+print(f"B={B} T={T}: rollout (forward + sampler) {t_f:.1f} us, whole step {t_s:.1f} us  scores {h} grad {hg}")
