@@ -59,8 +59,17 @@ def clip_pixels(cfg, n_frames):
 # ---- scenarios shared by tests/test_gpu_ops.py / test_gpu_e2e.py (HIP vs fp32 oracle) and make_golden.py's `noise` group
 #      (the reference's own bf16 path vs fp32 on the SAME pixels / weights / text): name -> (weights, frames, pixel seed) ----
 ENCODE_SCENARIOS = {"l14_normal_70": ("normal", 70, 4321), "l14_heavy_64": ("heavy_tailed", 64, 777)}
-E2E_SCENARIOS = {"normal": ("normal", 128, [9, 10, 40, 41, 42, 77, 100, 101]), "heavy_tailed": ("heavy_tailed", 64, [9, 10, 40, 41])}
+E2E_SCENARIOS = {"normal": ("normal", 128, [9, 10, 40, 41, 42, 77, 100, 101]), "heavy_tailed": ("heavy_tailed", 64, [9, 10, 40, 41]),
+                 # round 5: the heavy-tailed case on two more videos (one sample of the score error is a draw from a wide distribution)
+                 "heavy_tailed_s2": ("heavy_tailed", 64, [5, 6, 30, 31]), "heavy_tailed_s3": ("heavy_tailed", 64, [17, 18, 50, 51])}
+E2E_VIDEO_SEEDS = {"heavy_tailed_s2": 2064, "heavy_tailed_s3": 3064}     # default: 1000 + frames
 E2E_TAU, E2E_WINDOW, E2E_TEXT_SEED = 0.025, 12, 4242
+# configs[1] at FULL size (BASELINE.json: T = 1024 frames, CLIP-L/14, top-k 32): one video, the planted-scene text and an independent one
+FULL_T, FULL_NEEDLES, FULL_VIDEO_SEED, FULL_K = 1024, [100, 101, 102, 400, 401, 402, 700, 701, 900, 901], 51024, 32
+
+
+def e2e_video_seed(name):
+    return E2E_VIDEO_SEEDS.get(name, 1000 + E2E_SCENARIOS[name][1])
 
 
 def clip_l14_state(weights):

@@ -459,6 +459,77 @@ def gen_published(_out):
     print(f"published: -> {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+# ---- helpers of the `noise` and `full1024` groups: the reference's arithmetic in fp32 and in bf16 (its production dtype) ----
+def _clip_model(cfgd, state):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    cfg = CLIPVisionConfig(hidden_size=cfgd["hidden"], intermediate_size=cfgd["mlp"], num_hidden_layers=cfgd["layers"],
+                           num_attention_heads=cfgd["heads"], image_size=cfgd["image"], patch_size=cfgd["patch"],
+                           projection_dim=cfgd["proj"], hidden_act="quick_gelu", layer_norm_eps=1e-5, attn_implementation="eager")
+    model = CLIPVisionModelWithProjection(cfg).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
+    return model.to(torch.bfloat16)          # parameters rounded once; .float() below keeps the rounded values
+
+
+def _both(model, px, progress=None):
+    out32, out16 = [], []
+    with torch.no_grad():
+        for i in range(0, px.shape[0], 16):
+            out16.append(model(pixel_values=px[i:i + 16].to(torch.bfloat16)).image_embeds.float())
+            if progress and i % 128 == 0:
+                print(f"   {progress}: bf16 {i}/{px.shape[0]}", flush=True)
+        model.float()
+        for i in range(0, px.shape[0], 16):
+            out32.append(model(pixel_values=px[i:i + 16]).image_embeds)
+            if progress and i % 128 == 0:
+                print(f"   {progress}: fp32 {i}/{px.shape[0]}", flush=True)
+    return torch.cat(out32), torch.cat(out16)
+
+
+def _feat_stats(f32, f16):
+    cos = torch.nn.functional.cosine_similarity(f32, f16, dim=-1)
+    return {"err_over_range": float((f16 - f32).abs().max() / f32.abs().max()), "min_cos": float(cos.min()),
+            "range": float(f32.abs().max())}
+
+
+def _normalize_u8(u8):
+    from transformers.image_utils import OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
+    m = torch.tensor(OPENAI_CLIP_MEAN).view(1, 3, 1, 1)
+    sd = torch.tensor(OPENAI_CLIP_STD).view(1, 3, 1, 1)
+    return (torch.from_numpy(u8).float() / 255.0 - m) / sd
+
+
+def _head_both(f32, f16, txt, sel, window, tau):
+    """scores of the reference's scoring head: fp32 on the fp32 features, and bf16 module on the bf16 features"""
+    cs = torch.nn.CosineSimilarity(dim=-1)
+    with torch.no_grad():
+        c32 = cs(txt, f32)
+        s32, _ = ref_selector(768, 8, sel)(f32, txt, c32, window_size=window, score_tau=tau)
+        m16 = ref_selector(768, 8, sel).to(torch.bfloat16)
+        f16b, t16 = f16.to(torch.bfloat16), txt.to(torch.bfloat16)
+        c16 = cs(t16, f16b)
+        s16, _ = m16(f16b, t16, c16, window_size=window, score_tau=tau)
+    return s32, s16.float(), c32, c16.float()
+
+
+def _head_noise(f32, f16, txt, sel, window, tau):
+    tspo_like = TSPOModel.inference_ts
+    s32, s16, c32, c16 = _head_both(f32, f16, txt, sel, window, tau)
+    eps = float((s16 - s32).abs().max())
+    r = {"score_eps_logits": eps, "score_eps_cosine_units": eps * tau, "score_spread_logits": float(s32.max() - s32.min())}
+    for k in (8, 32):
+        a = quiet(tspo_like, None, s32, "topk", k)[0].tolist()
+        b = quiet(tspo_like, None, s16, "topk", k)[0].tolist()
+        r[f"top{k}_overlap_bf16_vs_fp32"] = len(set(a) & set(b))
+    # round 5: WHERE the score error comes from - the cosine clip score alone (in logits: / tau), the rest of the score (the
+    # scoring head's mean-cosine branch), and the feature error projected on the text direction (d . t^ / |f|: the first-order
+    # term of the cosine's error) - so a HIP-vs-reference difference can be attributed
+    r["clip_eps_logits"] = float((c16 - c32).abs().max() / tau)
+    r["head_eps_logits"] = float(((s16 - c16 / tau) - (s32 - c32 / tau)).abs().max())
+    th = torch.nn.functional.normalize(txt.float(), dim=-1)[0]
+    r["proj_err_max"] = float((((f16 - f32) @ th) / f32.norm(dim=-1)).abs().max())
+    return r
+
+
 def gen_noise(_out):
     """How far the REFERENCE'S OWN precision sits from fp32 (the reference runs CLIP and the scoring head in bf16:
     mp_tools/vlmeval/vlm/gen_id_tspo.py:55, src/open_tspo/trainer/tspo_trainer.py:201): the installed transformers CLIP and the
@@ -466,81 +537,35 @@ def gen_noise(_out):
     CPU on the SAME weights / pixels / text as the HIP-vs-oracle tests (tests/golden/inputs.py: ENCODE_SCENARIOS, E2E_SCENARIOS).
     The fp32 side carries the bf16-ROUNDED parameters (what both the bf16 model and the HIP encoder hold), so the deltas are
     arithmetic noise only.  Stored: feature error as a fraction of the fp32 feature range, the smallest per-frame cosine, the
-    score error in logits, and how many of the reference's own bf16 top-k indices differ from its fp32 ones.  The HIP
-    tolerances are tied to these (tests assert HIP-vs-fp32 <= 1.5 x) -> tests/golden/bf16_noise.json.  ~15 min of CPU."""
+    score error in logits (round 5: split into its clip-score and scoring-head parts), and how many of the reference's own bf16
+    top-k indices differ from its fp32 ones.  The HIP tolerances are tied to these (tests assert HIP-vs-fp32 <= 1.5 x per case,
+    median over the three heavy-tailed videos <= 1.25 x) -> tests/golden/bf16_noise.json.  ~20 min of CPU."""
     import json
-    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
-    from transformers.image_utils import OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
     from inputs import (ENCODE_SCENARIOS, E2E_SCENARIOS, E2E_TAU, E2E_WINDOW, clip_l14_state, e2e_video, e2e_selector_state,
-                        e2e_texts)
+                        e2e_texts, e2e_video_seed)
     g = {"clip": {}, "selector": {}, "encode": {}, "e2e": {}}
-    tspo_like = TSPOModel.inference_ts
     only_e2e = os.environ.get("TSPO_NOISE_ONLY_E2E") == "1"     # regenerate the end-to-end group only, keep the rest of the file
     if only_e2e:
         g = json.load(open(os.path.join(HERE, "bf16_noise.json")))
         g["e2e"] = {}
 
-    def clip_model(cfgd, state):
-        cfg = CLIPVisionConfig(hidden_size=cfgd["hidden"], intermediate_size=cfgd["mlp"], num_hidden_layers=cfgd["layers"],
-                               num_attention_heads=cfgd["heads"], image_size=cfgd["image"], patch_size=cfgd["patch"],
-                               projection_dim=cfgd["proj"], hidden_act="quick_gelu", layer_norm_eps=1e-5, attn_implementation="eager")
-        model = CLIPVisionModelWithProjection(cfg).eval()
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
-        return model.to(torch.bfloat16)          # parameters rounded once; .float() below keeps the rounded values
-
-    def both(model, px):
-        out32, out16 = [], []
-        with torch.no_grad():
-            for i in range(0, px.shape[0], 16):
-                out16.append(model(pixel_values=px[i:i + 16].to(torch.bfloat16)).image_embeds.float())
-            model.float()
-            for i in range(0, px.shape[0], 16):
-                out32.append(model(pixel_values=px[i:i + 16]).image_embeds)
-        return torch.cat(out32), torch.cat(out16)
-
-    def stats(f32, f16):
-        cos = torch.nn.functional.cosine_similarity(f32, f16, dim=-1)
-        return {"err_over_range": float((f16 - f32).abs().max() / f32.abs().max()), "min_cos": float(cos.min()),
-                "range": float(f32.abs().max())}
-
-    def normalize_u8(u8):
-        m = torch.tensor(OPENAI_CLIP_MEAN).view(1, 3, 1, 1)
-        sd = torch.tensor(OPENAI_CLIP_STD).view(1, 3, 1, 1)
-        return (torch.from_numpy(u8).float() / 255.0 - m) / sd
-
-    def head_noise(f32, f16, txt, sel):
-        cs = torch.nn.CosineSimilarity(dim=-1)
-        with torch.no_grad():
-            s32, _ = ref_selector(768, 8, sel)(f32, txt, cs(txt, f32), window_size=E2E_WINDOW, score_tau=E2E_TAU)
-            m16 = ref_selector(768, 8, sel).to(torch.bfloat16)
-            f16b, t16 = f16.to(torch.bfloat16), txt.to(torch.bfloat16)
-            s16, _ = m16(f16b, t16, cs(t16, f16b), window_size=E2E_WINDOW, score_tau=E2E_TAU)
-        s16 = s16.float()
-        eps = float((s16 - s32).abs().max())
-        r = {"score_eps_logits": eps, "score_eps_cosine_units": eps * E2E_TAU, "score_spread_logits": float(s32.max() - s32.min())}
-        for k in (8, 32):
-            a = quiet(tspo_like, None, s32, "topk", k)[0].tolist()
-            b = quiet(tspo_like, None, s16, "topk", k)[0].tolist()
-            r[f"top{k}_overlap_bf16_vs_fp32"] = len(set(a) & set(b))
-        return r
-
     # small models: the golden CLIP cases
     for tag, cfgd, n in ([] if only_e2e else CLIP_CASES[:2]):
         for wname, state in (("normal", synth.clip_vision_state(**cfgd)), ("heavy_tailed", synth.clip_vision_state_heavy_tailed(cfgd))):
-            f32, f16 = both(clip_model(cfgd, state), torch.from_numpy(clip_pixels(cfgd, n)[1]))
-            g["clip"][f"{tag}.{wname}"] = dict(stats(f32, f16), frames=n)
+            f32, f16 = _both(_clip_model(cfgd, state), torch.from_numpy(clip_pixels(cfgd, n)[1]))
+            g["clip"][f"{tag}.{wname}"] = dict(_feat_stats(f32, f16), frames=n)
             print(tag, wname, g["clip"][f"{tag}.{wname}"], flush=True)
     # CLIP-L/14 on the pixels of the HIP encode tests
     for name, (wname, n, seed) in ({} if only_e2e else ENCODE_SCENARIOS).items():
-        f32, f16 = both(clip_model(synth.CLIP_L14, clip_l14_state(wname)), normalize_u8(synth.uniform_u8((n, 3, 224, 224), seed)))
-        g["encode"][name] = dict(stats(f32, f16), frames=n)
+        f32, f16 = _both(_clip_model(synth.CLIP_L14, clip_l14_state(wname)), _normalize_u8(synth.uniform_u8((n, 3, 224, 224), seed)))
+        g["encode"][name] = dict(_feat_stats(f32, f16), frames=n)
         print("encode", name, g["encode"][name], flush=True)
     # the whole pipeline (bf16 encode -> bf16 scoring head) on the end-to-end test's videos, planted-scene and independent text
     sel = e2e_selector_state()
     for name, (wname, n, needles) in E2E_SCENARIOS.items():
-        f32, f16 = both(clip_model(synth.CLIP_L14, clip_l14_state(wname)), normalize_u8(e2e_video(n, needles, 1000 + n)))
-        per_text = {tn: head_noise(f32, f16, tx, sel) for tn, tx in e2e_texts(f32, needles).items()}
-        g["e2e"][name] = {"frames": n, "tau": E2E_TAU, "features": stats(f32, f16), "texts": per_text,
+        f32, f16 = _both(_clip_model(synth.CLIP_L14, clip_l14_state(wname)), _normalize_u8(e2e_video(n, needles, e2e_video_seed(name))))
+        per_text = {tn: _head_noise(f32, f16, tx, sel, E2E_WINDOW, E2E_TAU) for tn, tx in e2e_texts(f32, needles).items()}
+        g["e2e"][name] = {"frames": n, "tau": E2E_TAU, "features": _feat_stats(f32, f16), "texts": per_text,
                           "max_score_eps_logits": max(v["score_eps_logits"] for v in per_text.values())}
         print("e2e", name, g["e2e"][name], flush=True)
     for name, T, D, H, w, tau, M, ks in ([] if only_e2e else SELECTOR_CASES):
@@ -558,9 +583,49 @@ def gen_noise(_out):
     print(f"noise: -> {path}")
 
 
+def gen_full1024(out):
+    """BASELINE.json configs[1] at FULL size through the reference's own chain (model/temporal_agent.py:177-192: extract_feature ->
+    temporal_sampling -> inference_ts; mp_tools/vlmeval/vlm/gen_id_tspo.py:55 for the bf16 production dtype): 1024 frames of the
+    end-to-end test's block video -> installed transformers CLIP-L/14 (fp32 arithmetic on the bf16-rounded parameters) -> cosine clip
+    score -> imported MultiModal_Align -> TSPOModel.inference_ts top-32 / top-64 / bin-max-32, for the planted-scene text (stored:
+    it is built from the fp32 features) and an independent N(0,1) text; and the SAME chain in bf16, so the fixture also holds the
+    reference's own score noise at this size.  A few KB of arrays -> tests/golden/full1024.npz.  ~25 min of CPU (8 threads)."""
+    from inputs import (FULL_T, FULL_NEEDLES, FULL_VIDEO_SEED, FULL_K, E2E_TAU, E2E_WINDOW, clip_l14_state, e2e_video,
+                        e2e_selector_state, e2e_independent_text)
+    tspo_like = TSPOModel.inference_ts
+    u8 = e2e_video(FULL_T, FULL_NEEDLES, FULL_VIDEO_SEED)
+    f32, f16 = _both(_clip_model(synth.CLIP_L14, clip_l14_state("normal")), _normalize_u8(u8), progress="full1024")
+    sel = e2e_selector_state()
+    planted = torch.nn.functional.normalize(f32[FULL_NEEDLES].mean(0, keepdim=True) - f32.mean(0, keepdim=True), dim=-1)
+    texts = {"planted": planted, "independent": torch.from_numpy(e2e_independent_text(0))}
+    st = _feat_stats(f32, f16)
+    out["feat.err_over_range_bf16"] = np.array(st["err_over_range"])
+    out["feat.min_cos_bf16"] = np.array(st["min_cos"])
+    out["feat.range"] = np.array(st["range"])
+    rows = [0, 1, 100, 511, 900, 1023]
+    out["feat.rows"] = np.array(rows, np.int64)
+    out["feat.values"] = f32[rows].numpy()
+    out["feat.row_norms"] = f32.norm(dim=-1).numpy()
+    out["feat.sum"] = np.array([f32.double().sum().item(), f32.double().abs().sum().item()])
+    out["u8.checksum"] = np.array([int(u8.astype(np.uint64).sum()), int(u8[::97].astype(np.uint64).sum())], np.uint64)
+    for tn, tx in texts.items():
+        s32, s16, c32, c16 = _head_both(f32, f16, tx, sel, E2E_WINDOW, E2E_TAU)
+        out[f"{tn}.text"] = tx.numpy()
+        out[f"{tn}.scores"] = s32.numpy()
+        out[f"{tn}.clip"] = c32.numpy()
+        out[f"{tn}.scores_bf16"] = s16.numpy()
+        for k in (len(FULL_NEEDLES), FULL_K, 64):
+            out[f"{tn}.topk{k}"] = quiet(tspo_like, None, s32, "topk", k)[0].numpy()
+            out[f"{tn}.topk{k}_bf16"] = quiet(tspo_like, None, s16, "topk", k)[0].numpy()
+        out[f"{tn}.binmax{FULL_K}"] = quiet(tspo_like, None, s32, "bin-max", FULL_K)[0].numpy()
+        out[f"{tn}.binmax{FULL_K}_bf16"] = quiet(tspo_like, None, s16, "bin-max", FULL_K)[0].numpy()
+        print(f"full1024 {tn}: eps(bf16 vs fp32) = {float((s16 - s32).abs().max()):.4f} logits, spread {float(s32.max() - s32.min()):.2f}; "
+              f"top-32 overlap {len(set(out[f'{tn}.topk32'].tolist()) & set(out[f'{tn}.topk32_bf16'].tolist()))}/32", flush=True)
+
+
 def main():
     groups = {"selector": gen_selector, "misc": gen_misc, "gumbel": gen_gumbel, "train": gen_train, "clip": gen_clip,
-              "glue": gen_glue, "published": gen_published, "noise": gen_noise}
+              "glue": gen_glue, "published": gen_published, "noise": gen_noise, "full1024": gen_full1024}
     which = sys.argv[1:] or list(groups)
     for g in which:
         out = {}

@@ -77,34 +77,44 @@ def test_shipped_library_has_no_dev_hooks():
     l = _lib.lib()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    for variant in (2, 6, 8, 9, 60, 67, 69, 70, 71, 72, 74, 75, 76, 78, 85):   # retired kernels / ablations / probes and the DMA-kernel lab schedules
+    assert b.built_mode() == "product", "the library on disk is a --dev build (python -m tspo_amd.build rebuilds the shipped one)"
+    for variant in (2, 6, 8, 9, 60, 67, 69, 70, 71, 72, 74, 75, 76, 78, 82, 85):   # retired kernels / ablations / probes, the DMA-kernel lab schedules, the round-2 register-staged kernel
         assert l.tspo_gemm_bf16(p, p, p, None, p, _lib.TSPO_BF16, 4096, 4096, 1024, variant << 8, None) == -1
         assert b"not part of this build" in l.tspo_last_error(), (variant, l.tspo_last_error())
     blob = open(_lib.LIB_PATH, "rb").read()
     for name in (b"gemm_bf16_p3_kernel", b"gemm_bf16_s256_kernel", b"gemm_bf16_w16_kernel", b"gemm_bf16_p256_kernel", b"clip_attn257p_kernel",
                  b"clip_attn257w8_kernel", b"TSPO_GEMM_VARIANT", b"TSPO_ATTN_ABL", b"TSPO_SEL_SPLIT", b"getenv", b"tspo_dma_set_debug",
-                 b"tspo_lab_gemm_dma\0tspo_dev"):
+                 b"tspo_lab_gemm_dma\0tspo_dev", b"gemm_bf16_a7_kernel", b"gemm_bf16_a9lab_kernel"):
         assert name not in blob, name
     for sym in ("tspo_dma_set_debug", "tspo_dev_set_debug"):
         assert not hasattr(l, sym), sym
-    assert b"gemm_bf16_a9_kernel" in blob and b"gemm_bf16_a7_kernel" in blob
+    assert b"gemm_bf16_a9_kernel" in blob
 
 
-@pytest.mark.parametrize("src,kernel", [("gemm_dma.hip", "gemm_bf16_a9_kernel"), ("gemm_agpr.hip", "gemm_bf16_a7_kernel")])
-def test_agpr_gemm_code_audit(tmp_path, src, kernel):
-    """gemm_dma.hip (production) and gemm_agpr.hip keep 256 accumulators per lane in AGPRs under literal names that the compiler
-    does not know about.  That is only sound if hipcc itself never touches an AGPR in those kernels and does not spill inside
-    the MFMA loop: audit the generated gfx950 code of every instantiation (device-only -S compile, ~1-2 min each).  For the
-    LDS-DMA kernel also: the only m0 writes are the ones in front of its own DMA instructions."""
+# SGPR spills (v_writelane / v_readlane into a spare VGPR, no memory traffic) hipcc leaves in each epilogue form of the production GEMM:
+# none in the steady-state K-step of any form; the counts below are prologue / tile-switch / epilogue / remainder-phase code.  An
+# upper bound per form, so that DESIGN.md cannot drift from the binary again.
+A9_SGPR_SPILL_BOUND = {0: 0, 1: 0, 2: 8, 3: 0, 4: 12, 5: 4, 6: 4, 7: 64, 8: 0}
+
+
+def test_agpr_gemm_code_audit(tmp_path):
+    """gemm_dma.hip (production) keeps 256 accumulators per lane in AGPRs under literal names that the compiler does not know
+    about.  That is only sound if hipcc itself never touches an AGPR in the kernel and does not spill inside the MFMA loop: audit
+    the generated gfx950 code of every instantiation (device-only -S compile, ~1-2 min).  Also: the only m0 writes are the ones in
+    front of its own DMA instructions; no scratch at all; no VGPR spills; SGPR spills bounded per form and absent from the
+    steady-state K-step; and the same register checks for the encoder's attention kernel."""
     import subprocess
     from tspo_amd import build as b
+    src, kernel = "gemm_dma.hip", "gemm_bf16_a9_kernel"
     asm = tmp_path / (src + ".s")
     subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
                            os.path.join(b.CSRC, src), "-o", str(asm)])
     txt = open(asm).read()
     kernels = re.findall(r"^(_ZN\S*%s\S*):[^\n]*\n(.*?)\n\.Lfunc_end" % kernel, txt, flags=re.S | re.M)
     assert len(kernels) == 9, [k[0] for k in kernels]   # the eight epilogue forms + the head-major q/k/v form (GE_BIAS_LN_HM)
+    meta = {m.group(1): m.group(2) for m in re.finditer(r"\.name:\s+(\S*%s\S*)\n(.*?)\.wavefront_size" % kernel, txt, flags=re.S)}
     for name, body in kernels:
+        epi = int(re.search(r"kernelILi(\d+)E", name).group(1))
         inasm, bad, m0bad = False, [], []
         blocks, cur = [], []
         for ln in body.split("\n"):
@@ -123,10 +133,37 @@ def test_agpr_gemm_code_audit(tmp_path, src, kernel):
             cur.append(t)
         blocks.append(cur)
         assert not bad, f"{name}: compiler-emitted AGPR access outside the asm statements: {bad[:3]}"
-        if kernel == "gemm_bf16_a9_kernel":
-            assert not m0bad, f"{name}: compiler-emitted m0 use next to the hand-written LDS-DMA: {m0bad[:3]}"
-            assert not any(x.startswith("scratch_") for blk in blocks for x in blk), f"{name}: scratch access"
-        for blk in blocks:
-            if sum(x.startswith("v_mfma") for x in blk) >= 32:       # the K-loop bodies
-                assert not any(x.startswith("scratch_") for x in blk), f"{name}: scratch access inside an MFMA block"
-        assert body.count("v_mfma_f32_16x16x32_bf16") >= (3 if kernel == "gemm_bf16_a9_kernel" else 6) * 64
+        assert not m0bad, f"{name}: compiler-emitted m0 use next to the hand-written LDS-DMA: {m0bad[:3]}"
+        assert not any(x.startswith("scratch_") for blk in blocks for x in blk), f"{name}: scratch access"
+        kblocks = [blk for blk in blocks if sum(x.startswith("v_mfma") for x in blk) >= 32]       # the K-step bodies
+        assert len(kblocks) == 3                                                                  # first / steady-state / last K-step of a tile
+        for blk in kblocks:
+            assert not any(x.startswith("scratch_") for x in blk), f"{name}: scratch access inside an MFMA block"
+        # the steady-state K-step = the block that branches back to itself: no SGPR spill traffic before its loop branch
+        steady = [blk for blk in kblocks if any(x.startswith("s_cbranch") and x.split()[-1] + ":" == blk[0].split()[0] for x in blk)]
+        assert len(steady) == 1, name
+        upto = max(i for i, x in enumerate(steady[0]) if x.startswith("v_mfma"))
+        assert not any("v_readlane" in x or "v_writelane" in x for x in steady[0][:upto]), f"{name}: SGPR spill traffic inside the steady-state K-step"
+        assert body.count("v_mfma_f32_16x16x32_bf16") >= 3 * 128 + 8
+        md = meta[name]
+        val = lambda key: int(re.search(key + r":\s+(\d+)", md).group(1))
+        assert val(r"\.vgpr_spill_count") == 0 and val(r"\.private_segment_fixed_size") == 0, name
+        assert val(r"\.sgpr_spill_count") <= A9_SGPR_SPILL_BOUND[epi], (name, val(r"\.sgpr_spill_count"))
+
+
+def test_attention_kernel_register_audit(tmp_path):
+    """clip_attn257_kernel (the encoder's attention at S = 257) must not spill: 256 VGPRs are all in use by design."""
+    import subprocess
+    from tspo_amd import build as b
+    asm = tmp_path / "clip_vit.s"
+    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                           os.path.join(b.CSRC, "clip_vit.hip"), "-o", str(asm)])
+    txt = open(asm).read()
+    found = 0
+    for m in re.finditer(r"\.name:\s+(\S*clip_attn257_kernel\S*)\n(.*?)\.wavefront_size", txt, flags=re.S):
+        md = m.group(2)
+        val = lambda key: int(re.search(key + r":\s+(\d+)", md).group(1))
+        found += 1
+        assert val(r"\.vgpr_spill_count") == 0 and val(r"\.private_segment_fixed_size") == 0 and val(r"\.sgpr_spill_count") == 0, \
+            (m.group(1), val(r"\.vgpr_spill_count"), val(r"\.private_segment_fixed_size"))
+    assert found >= 1

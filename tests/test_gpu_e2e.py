@@ -29,7 +29,8 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-from inputs import E2E_SCENARIOS, E2E_TAU, E2E_WINDOW, clip_l14_state, e2e_selector_state, e2e_texts, e2e_video  # noqa: E402
+from inputs import (E2E_SCENARIOS, E2E_TAU, E2E_WINDOW, FULL_K, FULL_NEEDLES, FULL_T, FULL_VIDEO_SEED, clip_l14_state,  # noqa: E402
+                    e2e_selector_state, e2e_texts, e2e_video, e2e_video_seed)
 from oracle import tspo_oracle as O
 from tspo_amd import ops, synth
 from tspo_amd.pipeline import FrameScorer
@@ -53,16 +54,34 @@ def _flat(sel):
     return flat.to(DEV)
 
 
-@pytest.mark.parametrize("weights", ["normal", "heavy_tailed"])
-def test_pixels_to_indices_oracle_vs_hip(weights):
+HEAVY = ["heavy_tailed", "heavy_tailed_s2", "heavy_tailed_s3"]
+_RATIOS = {}      # scenario -> (largest HIP score error over the six texts) / (the reference's own bf16 score error on the same video)
+
+
+def test_pixels_to_indices_normal_weights():
+    _pixels_to_indices("normal")
+
+
+def test_pixels_to_indices_heavy_tailed_three_videos():
+    """Heavy-tailed weights (outlier channels, LayerNorm gains up to 8, like trained CLIP checkpoints) on three videos: every
+    case within 1.5 x the reference's own bf16 score noise on that video, and the MEDIAN of the three within 1.25 x - one sample
+    of this ratio is a draw from a wide distribution (round 4 sat at x 1.49 on the first video alone)."""
+    for sc in HEAVY:
+        _pixels_to_indices(sc)
+    r = sorted(_RATIOS[sc] for sc in HEAVY)
+    print(f"\n[e2e heavy-tailed] HIP / reference-bf16 score-error ratios over the three videos: {[round(x, 3) for x in r]}, median {r[1]:.3f}")
+    assert r[1] <= 1.25, f"median ratio {r[1]}"
+
+
+def _pixels_to_indices(scenario):
     torch.set_num_threads(min(32, torch.get_num_threads()))
     cfg = synth.CLIP_L14
-    _, n, needles = E2E_SCENARIOS[weights]
-    noise = NOISE[weights]
+    weights, n, needles = E2E_SCENARIOS[scenario]
+    noise = NOISE[scenario]
     assert noise["frames"] == n
     state = clip_l14_state(weights)
     sel = e2e_selector_state()
-    u8 = e2e_video(n, needles, 1000 + n)
+    u8 = e2e_video(n, needles, e2e_video_seed(scenario))
 
     # ---- oracle: fp32 arithmetic on the checkpoint's bf16-rounded matrices -------------------------------------------
     wq = {k: (T_(v).to(torch.bfloat16).float() if v.ndim >= 2 and "position_embedding" not in k else T_(v)) for k, v in state.items()}
@@ -90,10 +109,11 @@ def test_pixels_to_indices_oracle_vs_hip(weights):
     ferr = (f_hip[0].cpu() - f_ref).abs().max().item() / f_ref.abs().max().item()
     eps = (s_hip - s_ref).abs().max().item()
     spread = (s_ref.max() - s_ref.min()).item()
-    print(f"\n[e2e {weights}, {n} frames] feature err {ferr:.4f} of range; score err eps = {eps:.4f} logits "
+    print(f"\n[e2e {scenario}, {n} frames] feature err {ferr:.4f} of range; score err eps = {eps:.4f} logits "
           f"(= {eps * TAU:.5f} in cosine units); oracle score spread {spread:.2f} logits")
     assert ferr < 3e-2
-    assert eps * TAU <= 0.02, f"end-to-end score error {eps * TAU} cosine units"
+    # free-standing ceiling in cosine units: 0.02, or - on the videos where the reference's own bf16 path sits above that - its noise
+    assert eps * TAU <= max(0.02, 1.1 * noise["max_score_eps_logits"] * TAU), f"end-to-end score error {eps * TAU} cosine units"
     # ---- the binding tolerance: the reference's own bf16-vs-fp32 noise on this video (tests/golden/bf16_noise.json) ----
     cosf = torch.nn.functional.cosine_similarity(f_hip[0].cpu(), f_ref, dim=-1).min().item()
     rf = noise["features"]
@@ -107,11 +127,22 @@ def test_pixels_to_indices_oracle_vs_hip(weights):
         sh = sh[0].cpu()
         e = (sh - sr.float()).abs().max().item()
         eps_by_text[tn] = e
+        # where the error comes from (round 5): the cosine clip score alone, the rest of the score (scoring head), and the
+        # feature error projected on the text direction - next to the same three numbers of the reference's own bf16 path
+        c_ref = O.clip_cosine_scores(tq, f_ref)
+        c_hip = O.clip_cosine_scores(tq, f_hip[0].cpu())
+        clip_e = (c_hip - c_ref).abs().max().item() / TAU
+        head_e = ((sh - c_hip / TAU) - (sr.float() - c_ref / TAU)).abs().max().item()
+        th = torch.nn.functional.normalize(tq.float(), dim=-1)[0]
+        proj = (((f_hip[0].cpu() - f_ref) @ th) / f_ref.norm(dim=-1)).abs().max().item()
         want32 = O.topk_sorted(sr.float(), 32).tolist()
         ov = len(set(i32[0].cpu().tolist()) & set(want32))
         rt = noise["texts"][tn]
         print(f"    text {tn:14s}: eps HIP {e:.4f} logits vs reference-bf16 {rt['score_eps_logits']:.4f}; top-32 overlap with fp32: "
               f"HIP {ov}/32, reference-bf16 {rt['top32_overlap_bf16_vs_fp32']}/32")
+        if "clip_eps_logits" in rt:
+            print(f"         {'':14s}  clip part {clip_e:.4f} (ref {rt['clip_eps_logits']:.4f}) | head part {head_e:.4f} (ref {rt['head_eps_logits']:.4f}) | "
+                  f"|d.t|/|f| {proj:.5f} (ref {rt['proj_err_max']:.5f})")
         if not tn.startswith("planted"):
             # an INDEPENDENT text (not derived from the oracle's own features): the band rule with its own eps
             order_t = torch.argsort(sr.float(), descending=True, stable=True)
@@ -123,6 +154,7 @@ def test_pixels_to_indices_oracle_vs_hip(weights):
     worst, ref_worst = max(eps_by_text.values()), noise["max_score_eps_logits"]
     print(f"    largest score error over the {len(texts)} texts: HIP {worst:.4f} logits, reference-bf16 {ref_worst:.4f} (x{worst / ref_worst:.2f})")
     assert worst <= 1.5 * ref_worst, f"score error {worst} logits > 1.5 x the reference's own bf16 noise {ref_worst}"
+    _RATIOS[scenario] = worst / ref_worst
 
     order = torch.argsort(s_ref, descending=True, stable=True)
     for k in (len(needles), 8, 32):

@@ -598,7 +598,7 @@ def test_gemm_bf16_persistent_kernel_full_check(N, K):
         want, kw = ref + R.float(), dict(residual=R.to(DEV))
     else:
         want, kw = ref, {}
-    for variant in (0, 82, 77):     # automatic choice; the four-wave AGPR kernels: register-staged / LDS-DMA operands (0 = 77 for big shapes)
+    for variant in (0, 77, 83):     # automatic choice (= 77 for big shapes); the LDS-DMA kernel with / without its remainder phase
         act = kw.get("act", 0) | (variant << 8)
         out = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=act).float().cpu()
         np.testing.assert_allclose(out.numpy(), want.numpy(), err_msg=f"variant {variant}", **tol)
@@ -626,6 +626,36 @@ def test_gemm_dma_kernel_edge_shapes(M, N, K):
             assert torch.equal(ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=act), out), what
         auto = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=kw.get("act_", 0))
         assert torch.equal(auto, out), f"{what}: the automatic choice for this shape is not the DMA kernel"
+        whole = ops.gemm_bf16(Ad, Wd, bias=bd, residual=kw.get("residual"), act=kw.get("act_", 0) | (83 << 8))
+        assert torch.equal(whole, out), f"{what}: remainder phase (64x64 sub-tiles) != whole tiles only"
+
+
+@pytest.mark.parametrize("N,K", [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)], ids=["qkv", "out", "fc1", "fc2"])
+def test_gemm_remainder_phase_bitwise_at_encoder_size(N, K):
+    """BASELINE configs[1] size: M = 257 x 1024 rows = 1 028 M-tiles, i.e. 16.06 / 48.19 / 64.25 rounds of 256 workgroups.  The
+    production kernel (77) runs whole rounds of 256x256 tiles and spreads the left-over tiles as 64x64 sub-tiles over all
+    workgroups; variant 83 runs the left-over tiles as a partial last round of whole tiles (the round-4 behaviour, verified element
+    by element against fp32 on smaller shapes above).  Same K order per element -> identical bits, for the bias / gelu / residual
+    epilogues; also at M = 262 144 (no remainder) and a ragged M."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for M in (257 * 1024, 262144, 257 * 1024 - 77):
+        A = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g, device=DEV) * 0.03).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g, device=DEV) * 0.1
+        R = torch.randn(M, N, generator=g, device=DEV).to(torch.bfloat16) if N == 1024 else None
+        act = 1 if N == 4096 else 0
+        a = ops.gemm_bf16(A, W, bias=bias, residual=R, act=act | (77 << 8))
+        b = ops.gemm_bf16(A, W, bias=bias, residual=R, act=act | (83 << 8))
+        assert torch.equal(a, b), (M, N, K)
+        assert torch.equal(a, ops.gemm_bf16(A, W, bias=bias, residual=R, act=act)), "automatic choice != production variant"
+        rows = torch.cat([torch.arange(M - 1100, M, device=DEV), torch.randint(0, M, (256,), device=DEV)])     # the left-over tiles' rows + a sample
+        want = A[rows].float() @ W.float().t() + bias
+        if act:
+            want = want * torch.sigmoid(1.702 * want)
+        if R is not None:
+            want = want + R[rows].float()
+        np.testing.assert_allclose(a[rows].float().cpu().numpy(), want.cpu().numpy(), rtol=1e-2, atol=2e-2)
+        del A, W, R, a, b
 
 
 def test_clip_vit_forward_70_frames_production_kernels():

@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtspo_hip.so")
-SOURCES = ["sampler.hip", "selector.hip", "gemm_bf16.hip", "gemm_agpr.hip", "gemm_dma.hip", "clip_vit.hip", "preprocess.hip"]
+SOURCES = ["sampler.hip", "selector.hip", "gemm_bf16.hip", "gemm_dma.hip", "clip_vit.hip", "preprocess.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_bf16.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "gemm_agpr_common.h"),
            os.path.join(CSRC, "gemm_dma_kernel.h"), os.path.join(os.path.dirname(PKG), "include", "tspo_hip.h")]
 
@@ -22,15 +22,26 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+DEV_SOURCES = ["dev/gemm_dma_lab.hip", "dev/gemm_agpr.hip"]      # compiled into the library only by build(dev=True) / `--dev`
+DEV_HEADERS = [os.path.join(CSRC, "dev", "gemm_dma_lab_kernel.h")]
+MODE_STAMP = LIB + ".mode"      # "product" | "dev": which build the .so on disk is (a dev library must never pass for the shipped one)
+
+
+def built_mode():
+    try:
+        return open(MODE_STAMP).read().strip()
+    except OSError:
+        return None
+
+
+def needs_build(dev: bool = False) -> bool:
+    if not os.path.exists(LIB) or built_mode() != ("dev" if dev else "product"):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    if dev:
+        deps += [os.path.join(CSRC, s) for s in DEV_SOURCES] + DEV_HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
-
-
-DEV_SOURCES = ["dev/gemm_dma_lab.hip"]      # compiled into the library only by build(dev=True) / `--dev`
 
 
 def build(force: bool = False, verbose: bool = True, dev: bool = False, only=None) -> str:
@@ -39,7 +50,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, only=Non
     variants of tools/bench_gemm.py need); the product sources themselves carry no conditional code and the shipped library
     is built WITHOUT them (tests/test_abi.py checks the binary).  only=[...] recompiles just those sources and relinks with
     the other objects as they are."""
-    if not force and not needs_build():
+    if not force and not needs_build(dev):
         return LIB
     hipcc = _hipcc()
     flags = os.environ.get("TSPO_EXTRA_HIPCC_FLAGS", "").split()
@@ -63,10 +74,12 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, only=Non
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(MODE_STAMP, "w") as f:
+        f.write("dev\n" if dev else "product\n")
     return LIB
 
 
 if __name__ == "__main__":
     only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
-    build(force=bool(only) or "--force" in sys.argv or "--dev" in sys.argv, dev="--dev" in sys.argv, only=only[0] if only else None)
+    build(force=bool(only) or "--force" in sys.argv, dev="--dev" in sys.argv, only=only[0] if only else None)
     print(LIB)

@@ -2,7 +2,7 @@
 // laboratory of the LDS-DMA GEMM - the schedules the production one was measured against, the no-DMA ablation (timing only, wrong
 // results), N-group overrides and the s_memtime probe of the K-step (tools/probe_gemm_dma.py).  Reached from gemm_dma.hip through
 // the weak symbol tspo_lab_gemm_dma.  Results: profiles/r4_a_gemm_dma_schedules_and_probes.txt, DESIGN 4.4.
-#include "../gemm_dma_kernel.h"
+#include "gemm_dma_lab_kernel.h"
 
 static void* g_dma_debug = nullptr;
 extern "C" void tspo_dma_set_debug(void* p) { g_dma_debug = p; }
@@ -48,7 +48,7 @@ template <int EPI>
 int lab_variant(const GemmArgs& g, hipStream_t st) {
   if (g.variant == 76) return launch_gemm_a9<EPI, LabThreeBarriers>(g, st);
   if (g.variant == 67) return launch_gemm_a9<EPI, LabVendorPositions>(g, st);
-  if (g.variant == 75) return launch_gemm_a9<EPI, A9ScheduleProduction, false, true>(g, st);   // production stream without its DMA instructions
+  if (g.variant == 75) return launch_gemm_a9lab<EPI, A9ScheduleProduction, false, true>(g, st);   // production stream without its DMA instructions
   if (g.variant == 73 || g.variant == 72 || g.variant == 71) {     // production schedule, N groups per XCD set forced to 1 / 4 / 8 (auto: 2 for wide N)
     GemmArgs h = g;
     h.ngrp = g.variant == 73 ? 1 : (g.variant == 72 ? 4 : 8);
@@ -58,7 +58,7 @@ int lab_variant(const GemmArgs& g, hipStream_t st) {
     GemmArgs h = g;
     h.pos = reinterpret_cast<const float*>(g_dma_debug);
     if (!h.pos) return tspo::set_err(TSPO_EINVAL, "gemm_dma: probe variant without a debug buffer (tspo_dma_set_debug)");
-    return launch_gemm_a9<EPI, A9ScheduleProduction, true>(h, st);
+    return launch_gemm_a9lab<EPI, A9ScheduleProduction, true>(h, st);
   }
   return tspo::set_err(TSPO_EINVAL, "gemm: kernel variant %d is not part of this build", g.variant);
 }

@@ -22,7 +22,7 @@ struct GemmArgs {
   const float* rstats;  // GE_*_LN: (rstd, -mean*rstd) per row of A [M][2]
   float* spart;         // GE_RESID_ST: per-slice (mean, M2) row statistics out [M][N/64][2]
   int M, N, K, tilesN, nwg, P;  // P: patches per frame (GE_PATCH row remap)
-  int variant;                  // 0 = auto; 1 = 128x128 small-problem kernel; 77 = 256x256 LDS-DMA operands; 82 = 256x256 register-staged
+  int variant;                  // 0 = auto; 1 = 128x128 small-problem kernel; 77 = 256x256 LDS-DMA operands; 83 = 77 without its remainder phase
   int ngrp;                     // 0 = auto N-group count per XCD
 };
 
@@ -31,8 +31,8 @@ namespace tspo {
 int gemm_bf16(int epi, const GemmArgs& g, hipStream_t st);
 // true when gemm_bf16 would run this shape on the persistent 256x256 kernel (the only one with the *_LN / *_ST epilogues)
 bool gemm_bf16_is_big(long M, int N, int K);
-// gemm_agpr.hip: the 4-wave kernel that keeps 256 accumulators per lane in AGPRs, register-staged operands (variant 82)
-int gemm_bf16_agpr(int epi, const GemmArgs& g, hipStream_t st);
-// gemm_dma.hip: the same tile with LDS-DMA operands (variant 77; 72-76 = schedule A/Bs and probes of a --dev build)
+// gemm_dma.hip: the persistent 256x256 four-wave kernel, 256 accumulators per lane in AGPRs, LDS-DMA operands (variant 77; 83 = the
+// same kernel with the remainder phase off: a partial last round of whole tiles, the round-4 behaviour; 67-76 = schedule A/Bs and
+// probes of a --dev build, 82 = the register-staged kernel of rounds 2-3, also --dev only)
 int gemm_bf16_dma(int epi, const GemmArgs& g, hipStream_t st);
 }

@@ -1,10 +1,13 @@
 // bf16 MFMA GEMMs of the CLIP encoder for gfx950 (MI355X): C = A * W^T with fused epilogues.
 // This file: the small-problem kernel (128x128x64, 2-stage LDS-DMA ring; projections, class-token rows, tiny models) and the
-// dispatcher.  Large problems (M*N >= 256^3, K >= 128) run on the persistent 256x256x64 four-wave kernels with AGPR accumulators:
-// gemm_dma.hip (LDS-DMA operands; production since round 4) and gemm_agpr.hip (register-staged operands; kept selectable as
-// variant 82).  The 8-wave ring kernel of rounds 1-2 and the round-1..3 A/B kernels are gone from the tree (their measurements:
-// DESIGN 4.1-4.3, profiles/r1_* .. r3_*; their code: git history up to 99eb127).
+// dispatcher.  Large problems (M*N >= 256^3, K >= 128) run on the persistent 256x256x64 four-wave kernel with AGPR accumulators and
+// LDS-DMA operands of gemm_dma.hip (production since round 4).  The register-staged kernel of rounds 2-3 lives in dev/gemm_agpr.hip
+// (variant 82 of a --dev build); the 8-wave ring kernel of rounds 1-2 and the round-1..3 A/B kernels are gone from the tree (their
+// measurements: DESIGN 4.1-4.3, profiles/r1_* .. r3_*; their code: git history up to 99eb127).
 #include "gemm_epilogue.h"
+
+// defined only by csrc/dev/gemm_agpr.hip (`python -m tspo_amd.build --dev`)
+extern "C" __attribute__((weak)) int tspo_lab_gemm_agpr(int epi, const GemmArgs* g, hipStream_t st);
 
 namespace {
 
@@ -156,13 +159,14 @@ int launch_gemm_v1(GemmArgs g, hipStream_t st) {
 
 
 // Kernel for "big" problems (gemm_bf16_is_big; K is a multiple of 64 at the ABI and at least 128 here): the four-wave AGPR
-// kernel with LDS-DMA operands of gemm_dma.hip (variant 77).  Variant 82 = the register-staged four-wave kernel of gemm_agpr.hip
-// (needs K % 128 == 0), variant 1 = the small-problem kernel above; the shipped library reads no environment variables.
+// kernel with LDS-DMA operands of gemm_dma.hip (variant 77; 83 = without its remainder phase, for A/B runs).  Variant 1 = the
+// small-problem kernel above; 82 = the register-staged kernel of rounds 2-3, present only in a --dev build (weak symbol, null
+// in the shipped library).  The shipped library reads no environment variables.
 template <int EPI>
 int launch_big(GemmArgs g, hipStream_t st) {
   if (g.variant == 0) g.variant = 77;
-  if (g.variant >= 67 && g.variant < 78) return tspo::gemm_bf16_dma(EPI, g, st);
-  if (g.variant == 82) return tspo::gemm_bf16_agpr(EPI, g, st);
+  if ((g.variant >= 67 && g.variant < 78) || g.variant == 83) return tspo::gemm_bf16_dma(EPI, g, st);
+  if (g.variant == 82 && tspo_lab_gemm_agpr) return tspo_lab_gemm_agpr(EPI, &g, st);
   return tspo::set_err(TSPO_EINVAL, "gemm: kernel variant %d is not part of this build", g.variant);
 }
 

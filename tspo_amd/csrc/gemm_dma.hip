@@ -1,5 +1,6 @@
 // bf16 MFMA GEMM for gfx950 (MI355X), LDS-DMA operand path ("a9", production since round 4): the kernel is the template of
-// gemm_dma_kernel.h; tile, wave layout, AGPR accumulators and epilogue are those of gemm_agpr.hip (gemm_agpr_common.h).
+// gemm_dma_kernel.h (whole 256x256 tiles in whole rounds + the 64x64 remainder phase of round 5); literal-AGPR MFMA statements and
+// the epilogue out of a[0:255]: gemm_agpr_common.h.
 #include "gemm_dma_kernel.h"
 
 // Defined only by the extra translation unit of a `python -m tspo_amd.build --dev` build (csrc/dev/gemm_dma_lab.hip): schedule
@@ -10,7 +11,7 @@ namespace {
 template <int EPI>
 int launch_a9_variant(const GemmArgs& g, hipStream_t st) {
   if (g.K < 2 * GT_BK) return tspo::set_err(TSPO_EINVAL, "gemm_dma: K=%d too small for the DMA kernel", g.K);
-  if (g.variant == 77) return launch_gemm_a9<EPI, A9ScheduleProduction>(g, st);
+  if (g.variant == 77 || g.variant == 83) return launch_gemm_a9<EPI, A9ScheduleProduction>(g, st);   // 83: remainder phase off
   if (tspo_lab_gemm_dma) return tspo_lab_gemm_dma(EPI, &g, st);
   return tspo::set_err(TSPO_EINVAL, "gemm: kernel variant %d (epilogue %d) is not part of this build", g.variant, EPI);
 }

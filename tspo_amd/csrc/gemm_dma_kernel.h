@@ -1,5 +1,6 @@
-// Internal: the LDS-DMA operand-path GEMM kernel ("a9") as a template - instantiated by gemm_dma.hip (production schedule) and,
-// in --dev builds, by dev/gemm_dma_lab.hip (schedule A/Bs, the no-DMA ablation, the s_memtime probe).
+// Internal: the LDS-DMA operand-path GEMM kernel ("a9") as a template over its K-step schedule - instantiated by gemm_dma.hip
+// (production schedule) and, in --dev builds, by dev/gemm_dma_lab.hip (schedule A/Bs; the instrumented copy of the kernel - no-DMA
+// ablation, s_memtime probe - lives in dev/gemm_dma_lab_kernel.h, not here).
 #pragma once
 #include "gemm_agpr_common.h"
 
@@ -26,6 +27,12 @@ namespace {
 // hides about three issue slots per 16-cycle MFMA, and the measured cost of a K-step follows the densest stretch of its
 // memory instructions, not their number (a one-barrier schedule with 32 memory instructions behind 32 consecutive MFMAs ran
 // 5-8 % slower than the three-barrier one; s_memtime probe: a barrier costs 20-40 cycles, the vmcnt wait 0).
+// Measured (profiles/r5_a_gemm_tail_ab.txt, same box, interleaved): a partial last round of whole tiles costs 0.18-0.48 tile-times
+// (not 1: its lone workgroups run on an otherwise idle chip), ONE sub-tile per workgroup 0.10-0.12 (out-proj 16.48 -> 16.12, fc2
+// 16.36 -> 16.10 tile-times), THREE (QKV) 0.49 against 0.18, FOUR (fc1) 0.60 against 0.46 - so the remainder phase runs only
+// when the left-over tiles make at most one sub-tile per workgroup.
+#define A9_TAIL_MAX_SUBTILES 1
+
 enum : int {
   OP_NONE = 0,
   OP_RA1 = 1,    // +j: A fragment j of K-half 1 <- current buffer
@@ -72,9 +79,98 @@ struct A9ScheduleProduction {
   }
 };
 
-// NODMA (--dev builds, timing only, wrong results): the same stream without its DMA instructions.
-template <int EPI, class SCHED, bool PROBE = false, bool NODMA = false>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int tilesM, int ngrp) {
+// ---------------------------------------------------------------------------------------------------------------------------
+// Remainder phase (round 5).  Whole 256x256 tiles are handed out in whole ROUNDS only: XCD set x owns ntile_x tiles, its 32
+// workgroups run floor(ntile_x / 32) of them each.  What is left over (out-proj / fc2 of the encoder: 4 112 tiles = 16.06 rounds,
+// i.e. 16 tiles for which the persistent loop used to run a 17th round at 1/16 occupancy) is cut into 64x64 SUB-tiles - 16 per
+// tile - and spread over ALL workgroups of the launch: no cross-workgroup reduction, every output element keeps its K order
+// (bitwise the results of the whole-tile path).  A sub-tile: 4 waves x (16 rows x 64 columns) - the shape g3_epi_row finishes, so
+// every epilogue form incl. the per-64-column-slice row statistics works unchanged - operands by LDS-DMA into an 8-deep ring of
+// 16 KB stages (the whole 128 KB), 7 stages in flight, one counted vmcnt + one barrier per K-step.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define A9T_STAGE 16384        // 64 A rows | 64 W rows, 128 B each
+#define A9T_DEPTH 8
+
+struct A9Remainder { int total; int pre[9]; int rounds[8]; };   // tiles left over per XCD set (prefix sums), whole rounds per set
+__host__ __device__ inline A9Remainder a9_remainder(int tilesM, int tilesN, int ngrp, int nwl) {
+  A9Remainder r{};
+  const int npset = 8 / ngrp, n_per = tilesN / ngrp;
+  for (int x = 0; x < 8; ++x) {
+    const int pset = x / ngrp;
+    const int panels = tilesM > pset ? (tilesM - pset + npset - 1) / npset : 0;
+    const int nt = panels * n_per;
+    r.rounds[x] = nt / nwl;
+    r.pre[x + 1] = r.pre[x] + nt % nwl;
+  }
+  r.total = r.pre[8];
+  return r;
+}
+
+template <int EPI>
+__device__ __forceinline__ void a9_tail_subtile(const GemmArgs& g, char* lds, int m_s, int n_s, int wid, int lane) {
+  const int l15 = lane & 15, q4 = lane >> 4, rin = lane >> 3, slot = lane & 7;
+  const int nk = g.K / GT_BK;
+  // waves 0, 1 bring the A rows (pieces 0-7 of a stage), waves 2, 3 the W rows (pieces 8-15): ONE descriptor per wave
+  const bool isw = wid >= 2;
+  const bf16_t* base = isw ? g.W + (size_t)n_s * g.K : g.A + (size_t)m_s * g.K;
+  const long left = (long)(isw ? g.N - n_s : g.M - m_s) * g.K * 2;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(left < 0x40000000L ? left : 0x40000000L), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0, 0x00020000);   // past the last K-step
+  const unsigned lane_goff = ((unsigned)rin * (unsigned)g.K + (unsigned)((slot ^ rin) << 3)) * 2u;
+  const unsigned piece_stride = 8u * (unsigned)g.K * 2u;
+  const unsigned so0 = (unsigned)(wid & 1) * 4u * piece_stride;
+  const unsigned lds_w = (unsigned)(size_t)lds + (unsigned)wid * 4096u;
+  auto issue = [&](int st) {   // this wave's 4 pieces of stage st -> ring slot st % DEPTH
+    const unsigned bb = lds_w + (unsigned)(st & (A9T_DEPTH - 1)) * A9T_STAGE;
+    const unsigned vo = lane_goff + (unsigned)st * (GT_BK * 2u);
+    const __amdgpu_buffer_rsrc_t r = st < nk ? rs : rz;
+#define A9T_PIECE(Q)                                                                                  \
+    asm volatile("s_add_u32 m0, %0, %1" ::"s"(bb), "i"((Q) * 1024) : "scc");                             \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(r), "s"(so0 + (Q) * piece_stride) : "memory")
+    A9T_PIECE(0); A9T_PIECE(1); A9T_PIECE(2); A9T_PIECE(3);
+#undef A9T_PIECE
+  };
+  // the previous user of the LDS (main loop / previous sub-tile) is done everywhere, and nothing of this wave is in flight
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int st = 0; st < A9T_DEPTH - 1; ++st) issue(st);
+  f32x4 acc[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int sw = l15 & 7;
+  const int offA = (wid * 16 + l15) * 128, offW = 8192 + l15 * 128;
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt landed (6 younger stages x 4 DMAs may fly) - for every wave; and everybody is done with ring slot (kt - 1) % DEPTH
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(4 * (A9T_DEPTH - 2)) : "memory");
+    issue(kt + A9T_DEPTH - 1);
+    const char* cur = lds + (kt & (A9T_DEPTH - 1)) * A9T_STAGE;
+    bf16x8 fa[2], fw[2][4];      // both K-halves first (one LDS latency per K-step), then the 8 MFMAs
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const int co = ((kh * 4 + q4) ^ sw) << 4;
+      fa[kh] = *reinterpret_cast<const bf16x8*>(cur + offA + co);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fw[kh][ni] = *reinterpret_cast<const bf16x8*>(cur + offW + ni * 2048 + co);
+    }
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)   // inline asm with VGPR accumulators: hipcc must not pick AGPRs in this kernel (it would for the builtin)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[ni]) : "v"(fw[kh][ni]), "v"(fa[kh]));
+  }
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first VALU read (the hazard recogniser does not see asm MFMAs)
+  const int m = m_s + wid * 16 + l15;
+  EpiCols ec;
+  g3_epi_cols<EPI>(g, n_s, 0, q4, ec);
+  const float2 rst = epi_is_ln(EPI) ? g3_epi_rowstat(g, m) : make_float2(1.f, 0.f);
+  g3_epi_row<EPI, false, false>(g, acc, ec, rst, m, n_s, 0, q4, g.bias);
+}
+
+// tail: 0 = every tile of an XCD set is a whole tile (the round-4 behaviour: a partial last round); 1 = whole rounds + the
+// remainder phase above.  launch_gemm_a9 chooses (g.variant 83 forces 0).
+template <int EPI, class SCHED>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int tilesM, int ngrp, int tail) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G3_STAGE];  // the ONLY LDS object
   constexpr A9Sched SC = SCHED::make();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -86,10 +182,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
   const int grp = xcd % ngrp, pset = xcd / ngrp, npset = 8 / ngrp, n_per = g.tilesN / ngrp;
   const int panels = (tilesM - pset + npset - 1) / npset;
   const int ntile_x = panels * n_per;
-  const int my_tiles = wl < ntile_x ? (ntile_x - wl + nwl - 1) / nwl : 0;
-  if (my_tiles == 0) return;
+  const int lim = tail ? (ntile_x / nwl) * nwl : ntile_x;   // tiles of this XCD set that are run as whole tiles
+  const int my_tiles = wl < lim ? (lim - wl + nwl - 1) / nwl : 0;
+  if (my_tiles == 0 && !tail) return;
   A4_FENCE();   // claims a[0:255] for this kernel
 
+  if (my_tiles > 0) {
   // ---- LDS-DMA: piece P = wid*8 + q of a region = rows 8P..8P+7 (1 KB); lane (rin, slot) brings global chunk slot ^ rin.
   //      Address split: voffset = lane part + K-step (ONE v_add per K-step), soffset = piece (loop-invariant SGPRs, the same
   //      for A and W), m0 = LDS destination (one s_add with a literal per piece) ----
@@ -99,16 +197,18 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
   unsigned lds0 = (unsigned)(size_t)lds + (unsigned)wid * 8192u;
   unsigned soff0 = (unsigned)wid * 8u * piece_stride;
   int d_kt = 0, d_s = wl;   // the stage the NEXT K-step's DMA brings: K-step inside the tile, tile
-  auto rsrc_a = [&](int s_) {
+  auto rsrc_a = [&](int s_) {   // (tiles at or past `lim` - the two stages requested past the last whole tile - get zero-length resources)
     const int m0 = ((s_ / n_per) * npset + pset) * G3_BM;
-    const long r = m0 < g.M ? ((long)(g.M - m0) * g.K * 2) : 0;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)(m0 < g.M ? m0 : 0) * g.K), 0,
+    const bool in = s_ < lim && m0 < g.M;
+    const long r = in ? ((long)(g.M - m0) * g.K * 2) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)(in ? m0 : 0) * g.K), 0,
                                              (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
   };
   auto rsrc_w = [&](int s_) {
     const int n0 = (grp * n_per + s_ % n_per) * G3_BN;
-    const long r = n0 < g.N ? ((long)(g.N - n0) * g.K * 2) : 0;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)(n0 < g.N ? n0 : 0) * g.K), 0,
+    const bool in = s_ < lim && n0 < g.N;
+    const long r = in ? ((long)(g.N - n0) * g.K * 2) : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)(in ? n0 : 0) * g.K), 0,
                                              (int)(r < 0x40000000L ? r : 0x40000000L), 0x00020000);
   };
   __amdgpu_buffer_rsrc_t a_rs = rsrc_a(d_s), w_rs = rsrc_w(d_s);
@@ -122,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
   auto set_m0 = [&](auto q_, auto isw_, unsigned bufbase) {
     constexpr int off = decltype(q_)::value * 1024 + (decltype(isw_)::value ? G3_BM * 128 : 0);
     const unsigned b = bufbase;
-    if (!NODMA) asm volatile("s_add_u32 m0, %0, %1" ::"s"(b), "i"(off) : "scc");
+    asm volatile("s_add_u32 m0, %0, %1" ::"s"(b), "i"(off) : "scc");
   };
   auto dma = [&](auto q_, auto isw_, unsigned voff) {
     constexpr int q = decltype(q_)::value;
@@ -131,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
     const __amdgpu_buffer_rsrc_t rs = isw ? w_rs : a_rs;
     // default cache policy on purpose: `nt` on the A or the W stream cuts the QKV form's L2-side fetch by a third (3.7 -> 2.5 GB per
     // launch) and is 2-6 % SLOWER on every shape; sc1 / sc0 sc1 change nothing (profiles/r4_g_fetch_calibration_and_cache_policy.txt)
-    if (!NODMA) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so) : "memory");
   };
 
   // ---- fragments: both K-halves of a stage, A and W: 4 x 8 x 4 VGPRs ----
@@ -155,18 +255,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
   for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(lds + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(lds + fbaseW + i * 2048 + co0); }
 
   int it = 0, c_s = wl;
-  // PROBE (--dev builds, csrc/dev/gemm_dma_lab.hip): s_memtime cycles per K-step and inside each synchronisation point, summed per wave
-  unsigned long long pr_ks = 0, pr_n = 0, pr_b1 = 0, pr_b2 = 0, pr_vm = 0, pr_b3 = 0, pr_vmz = 0, pr_nz = 0, pr_vm1 = 0, pr_epi = 0, pr_tile = 0;
-  int pr_kt = 0;
-  auto stamp = [&]() {
-    unsigned long long t = 0;
-    if (PROBE) { t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-    return t;
-  };
   auto kstep = [&](auto zero_, auto last_) {
     constexpr bool ZERO = decltype(zero_)::value, LAST = decltype(last_)::value;
     const int cb = it & 1;
-    const unsigned long long pr_t0 = stamp();
     const char* cur = lds + cb * G3_STAGE;
     const char* nxt = lds + (cb ^ 1) * G3_STAGE;
     const unsigned vo = lane_goff + (unsigned)d_kt * (GT_BK * 2u), bb = lds0 + (unsigned)cb * G3_STAGE;
@@ -197,65 +288,71 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
           dma(std::integral_constant<int, op - OP_MDW>{}, std::true_type{}, vo);
         }
         if constexpr (op == OP_B1 || op == OP_B2) {   // every wave holds its A (B1) / W (B2) fragments of this stage -> region may be refilled
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const unsigned long long ta = stamp();
-          asm volatile("s_barrier" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           __builtin_amdgcn_s_waitcnt(0xC07F);
-          if (PROBE) { if (op == OP_B1) pr_b1 += stamp() - ta; else pr_b2 += stamp() - ta; }
         }
-        if constexpr (op == OP_B3) {   // this wave's pieces of stage it+1 have landed (SC.vm younger DMAs may fly) -> everybody's
-          const unsigned long long ta = stamp();
-          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SC.vm) : "memory");
-          const unsigned long long tb = stamp();
-          asm volatile("s_barrier" ::: "memory");
-          if (PROBE) {
-            const unsigned long long tc = stamp(); pr_vm += tb - ta; pr_b3 += tc - tb;
-            if (ZERO) { pr_vmz += tb - ta; ++pr_nz; }
-            if (pr_kt == 1) pr_vm1 += tb - ta;
-          }
-        }
+        if constexpr (op == OP_B3)   // this wave's pieces of stage it+1 have landed (SC.vm younger DMAs may fly) -> everybody's
+          asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(SC.vm) : "memory");
       });
       A4_FENCE();
     });
     adv_d();
     ++it;
-    if (PROBE) { pr_ks += stamp() - pr_t0; ++pr_n; pr_kt = LAST ? 0 : pr_kt + 1; }
   };
 
   for (int t = 0; t < my_tiles; ++t) {
     const int m0 = ((c_s / n_per) * npset + pset) * G3_BM, n0 = (grp * n_per + c_s % n_per) * G3_BN;
-    const unsigned long long pr_tt0 = stamp();
     kstep(std::true_type{}, std::false_type{});
     for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
     EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
     epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
     kstep(std::false_type{}, std::true_type{});
-    const unsigned long long pr_te0 = stamp();
     if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
     else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
-    if (PROBE) pr_epi += stamp() - pr_te0;
     c_s += nwl;
     const char* nbuf = lds + (it & 1) * G3_STAGE;              // the next tile's first fragments, behind the epilogue
 #pragma unroll
     for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(nbuf + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(nbuf + fbaseW + i * 2048 + co0); }
-    if (PROBE) pr_tile += stamp() - pr_tt0;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two stages requested past the last tile (zero-length resources)
-  if (PROBE && lane == 0 && g.pos) {
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(g.pos)) + ((size_t)blockIdx.x * 4 + wid) * 12;
-    o[9] = pr_epi; o[10] = pr_tile; o[11] = (unsigned long long)my_tiles;
-    o[0] = pr_ks; o[1] = pr_n; o[2] = pr_b1; o[3] = pr_b2; o[4] = pr_vm; o[5] = pr_b3; o[6] = pr_vmz; o[7] = pr_nz; o[8] = pr_vm1;
+  }
+
+  if (tail) {   // ---- remainder phase: the left-over tiles of all XCD sets as 64x64 sub-tiles over all workgroups ----
+    const A9Remainder rm = a9_remainder(tilesM, g.tilesN, ngrp, nwl);
+    for (int j = blockIdx.x; j < rm.total * 16; j += gridDim.x) {
+      const int tt = j >> 4, sub = j & 15;
+      int x = 0;
+#pragma unroll
+      for (int i = 1; i < 8; ++i) x += tt >= rm.pre[i] ? 1 : 0;
+      int rx = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rx = i == x ? rm.rounds[i] : rx;
+      int px = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) px = i == x ? rm.pre[i] : px;
+      const int s = rx * nwl + (tt - px);
+      const int m0 = ((s / n_per) * npset + x / ngrp) * G3_BM, n0 = ((x % ngrp) * n_per + s % n_per) * G3_BN;
+      const int m_s = m0 + (sub >> 2) * 64, n_s = n0 + (sub & 3) * 64;
+      if (m_s < g.M && n_s < g.N) a9_tail_subtile<EPI>(g, lds, m_s, n_s, wid, lane);   // (uniform per workgroup)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-length stages requested past the last K-step
   }
 }
 
-template <int EPI, class SCHED, bool PROBE = false, bool NODMA = false>
+template <int EPI, class SCHED>
 int launch_gemm_a9(GemmArgs g, hipStream_t st) {
   const int tilesM = (g.M + G3_BM - 1) / G3_BM;
   g.tilesN = (g.N + G3_BN - 1) / G3_BN;
   g.nwg = tilesM * g.tilesN;
   int ngrp = ((double)g.N * g.K * 2.0 > 4.0e6 && g.tilesN >= 8 && g.tilesN % 2 == 0) ? 2 : 1;
   if (g.ngrp > 0 && g.tilesN % g.ngrp == 0) ngrp = g.ngrp;
-  hipLaunchKernelGGL((gemm_bf16_a9_kernel<EPI, SCHED, PROBE, NODMA>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp);
+  // remainder phase when a partial last round exists, every XCD set has whole rounds to run, and the left-over tiles make at
+  // most A9_TAIL_MAX_SUBTILES 64x64 sub-tiles per workgroup (beyond that the partial round of whole tiles is cheaper: see above)
+  const A9Remainder rm = a9_remainder(tilesM, g.tilesN, ngrp, 32);
+  int min_rounds = rm.rounds[0];
+  for (int x = 1; x < 8; ++x) min_rounds = rm.rounds[x] < min_rounds ? rm.rounds[x] : min_rounds;
+  const int tail = (g.variant != 83 && rm.total > 0 && min_rounds >= 1 && rm.total * 16 <= A9_TAIL_MAX_SUBTILES * 256) ? 1 : 0;
+  hipLaunchKernelGGL((gemm_bf16_a9_kernel<EPI, SCHED>), dim3(256), dim3(256), 0, st, g, tilesM, ngrp, tail);
   return tspo::check_launch("gemm_bf16_a9");
 }
 
