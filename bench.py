@@ -154,6 +154,9 @@ def cpu_baseline(T, k):
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 
 
+LAST_RUNTIME_COPIES = {}     # memcpy / memset device records per call of the last count_kernel_launches (runtime work, not library kernels)
+
+
 def count_kernel_launches(fn, reps: int = 3):
     """Kernel launches of one call of `fn`, counted LIVE by the profiler's device-activity records (roctracer) over
     `reps` calls; returns (launches per call, {kernel name: launches per call}) or (None, reason) if tracing is
@@ -166,14 +169,21 @@ def count_kernel_launches(fn, reps: int = 3):
             for _ in range(reps):
                 fn()
             torch.cuda.synchronize()
-        names = {}
+        names, runtime = {}, {}
         for ev in prof.events():
-            if str(getattr(ev, "device_type", "")).endswith("CUDA") and ev.name and not ev.name.lower().startswith(("memcpy", "memset")):
-                short = ev.name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].split("::")[-1]
-                names[short] = names.get(short, 0) + 1
+            if not (str(getattr(ev, "device_type", "")).endswith("CUDA") and ev.name):
+                continue
+            if ev.name.lower().startswith(("memcpy", "memset")):     # the runtime's own copies / fills (not kernels of the library):
+                key = ev.name.split("(")[0].strip()                  # named and counted beside the kernels, not hidden
+                runtime[key] = runtime.get(key, 0) + 1
+                continue
+            short = ev.name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].split("::")[-1]
+            names[short] = names.get(short, 0) + 1
         total = sum(names.values())
         if total == 0 or total % reps:
             return None, f"profiler saw {total} device kernels over {reps} calls"
+        LAST_RUNTIME_COPIES.clear()
+        LAST_RUNTIME_COPIES.update({k: v / reps for k, v in sorted(runtime.items())})
         return total // reps, {k: v / reps for k, v in sorted(names.items())}
     except Exception as e:      # tracing unavailable (e.g. under rocprofv3): report why, never a made-up constant
         return None, f"{type(e).__name__}: {e}"
@@ -400,22 +410,40 @@ def dp_path_rollouts(flat, dev, world: int, rank: int, cfg, steps: int, timed) -
     ttxt = [torch.randn(1, 1, 768, generator=gen, device=dev) for _ in range(accum)]
     clip = [ops.clip_scores(t, f) for t, f in zip(ttxt, feats)]
     rew = [(torch.rand(1, G, generator=gen, device=dev) > 0.5).float() + torch.rand(1, G, generator=gen, device=dev) for _ in range(accum)]
-    trainer = PolicyTrainer(flat.clone(), grad_accum_steps=accum)
     seen = {}
+    # (a) coalesced (production since round 5, what tspo_amd.train does when the micro-batches stack): the two prompts of the
+    #     optimizer step as ONE stacked rollout / backward - same Philox draws per prompt, same weights (no update between the
+    #     reference's micro-steps, tspo_trainer.py:500-552)
+    f2, t2, c2, r2 = torch.cat(feats), torch.cat(ttxt), torch.cat(clip), torch.cat(rew)
+    trainer = PolicyTrainer(flat.clone(), grad_accum_steps=accum)
 
     def opt_step():
-        for i in range(accum):
-            st = trainer.step(feats[i], ttxt[i], clip[i], lambda idx, i=i: rew[i], G, kt, tau)
+        st = trainer.step(f2, t2, c2, lambda idx: r2, G, kt, tau, micro_steps=accum)
         seen["world"] = st["world"]
+
+    # (b) sequential (round 4): one rollout / backward per micro-step, the second accumulated into the bucket
+    trainer_seq = PolicyTrainer(flat.clone(), grad_accum_steps=accum)
+
+    def opt_step_seq():
+        for i in range(accum):
+            trainer_seq.step(feats[i], ttxt[i], clip[i], lambda idx, i=i: rew[i], G, kt, tau)
 
     n = max(steps, 200)
     sec = timed(opt_step, n, 3)
+    sec_seq = timed(opt_step_seq, n, 3)
     n_launch, by_kernel = (None, "counted on rank 0 of a single-rank job only") if (rank or world > 1) else count_kernel_launches(opt_step)
+    copies = dict(LAST_RUNTIME_COPIES) if n_launch else None
+    n_seq = None if (rank or world > 1) else count_kernel_launches(opt_step_seq)[0]
     return {"rollouts_per_s": round(accum * G * world * n / sec, 1), "us_per_optimizer_step": round(sec / n * 1e6, 1),
             "config": {"prompts_per_micro_step": 1, "grad_accum_steps": accum, "T": Tt, "G": G, "k": kt, "ranks": world},
+            "variant": "coalesced micro-steps: the window's prompts as one stacked rollout / backward (indices bitwise those of the sequential path)",
             "allreduce": f"issued every optimizer step on the live {seen.get('world')}-rank process group (11.8 MB fp32 bucket)",
             "launches_per_optimizer_step": n_launch, "launches_by_kernel": by_kernel if n_launch else None,
+            "runtime_copies_per_optimizer_step": copies,
             "launches_note": None if n_launch else by_kernel,
+            "roofline": policy_step_roofline(accum, Tt, 768, sec / n, n_launch, by_kernel if n_launch else None),
+            "sequential": {"rollouts_per_s": round(accum * G * world * n / sec_seq, 1), "us_per_optimizer_step": round(sec_seq / n * 1e6, 1),
+                           "launches_per_optimizer_step": n_seq},
             "note": "the reference's configuration (train_deepspeed.sh:30-31); `rollouts_per_s` above is the fused single-rank variant"}
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TSPO_ABI_VERSION 3
+#define TSPO_ABI_VERSION 4
 
 enum tspo_error {
   TSPO_OK = 0,
@@ -84,6 +84,16 @@ int tspo_gumbel_topk(const float* logits, const float* noise, uint64_t seed, uin
                      int B, int G, int T, int k, float tau,
                      int64_t* idx, float* logp, float* probs, float* noise_out,
                      tspo_stream_t stream);
+
+/* ABI v4.  The same with the prompts of SEVERAL micro-steps in one call (the reference trains with
+ * per_device_train_batch_size 1 x gradient_accumulation_steps 2, train_deepspeed.sh:30-31; the two micro-steps see the same
+ * weights - no update between them, tspo_trainer.py:500-552 - so their policy math is one batch): prompts come in groups
+ * of `prompts_per_offset` (> 0, divides B); prompt b draws the in-kernel noise that prompt b % p of a separate call with
+ * offset + b / p would draw, so the coalesced rollouts are bit for bit the sequential ones.  0 = tspo_gumbel_topk.     */
+int tspo_gumbel_topk_ex(const float* logits, const float* noise, uint64_t seed, uint64_t offset,
+                        int B, int G, int T, int k, float tau,
+                        int64_t* idx, float* logp, float* probs, float* noise_out,
+                        tspo_stream_t stream, int prompts_per_offset);
 
 /* ------------------------------------------------------------------------
  * Group-relative advantage + policy-gradient reduction

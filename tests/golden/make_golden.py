@@ -594,9 +594,25 @@ def gen_full1024(out):
                         e2e_selector_state, e2e_independent_text)
     tspo_like = TSPOModel.inference_ts
     u8 = e2e_video(FULL_T, FULL_NEEDLES, FULL_VIDEO_SEED)
-    f32, f16 = _both(_clip_model(synth.CLIP_L14, clip_l14_state("normal")), _normalize_u8(u8), progress="full1024")
+    cache = os.environ.get("TSPO_FULL1024_CACHE")       # generation convenience: the two feature matrices (25 min of CPU) kept in a scratch file
+    if cache and os.path.exists(cache):
+        zz = np.load(cache)
+        f32, f16 = torch.from_numpy(zz["f32"]), torch.from_numpy(zz["f16"])
+    else:
+        f32, f16 = _both(_clip_model(synth.CLIP_L14, clip_l14_state("normal")), _normalize_u8(u8), progress="full1024")
+        if cache:
+            np.savez(cache, f32=f32.numpy(), f16=f16.numpy())
     sel = e2e_selector_state()
-    planted = torch.nn.functional.normalize(f32[FULL_NEEDLES].mean(0, keepdim=True) - f32.mean(0, keepdim=True), dim=-1)
+    # the "question" about the planted scene.  With 1024 shots the plain difference (scene - mean frame) of the 64 / 128-frame
+    # tests no longer singles the scene out (random-init CLIP features differ along few directions: some unrelated frames point
+    # further along it than the scene does), so the query is the Fisher direction C^-1 (scene - mean) - what a text feature
+    # trained to retrieve that scene would be.  Built in float64 from the fp32 features and STORED (the GPU test reads it).
+    mu = f32.double().mean(0)
+    X = f32.double() - mu
+    Cm = X.T @ X / X.shape[0]
+    Cm = Cm + 1e-3 * Cm.diagonal().mean() * torch.eye(Cm.shape[0], dtype=torch.float64)
+    wdir = torch.linalg.solve(Cm, f32[FULL_NEEDLES].double().mean(0) - mu)
+    planted = torch.nn.functional.normalize(wdir[None], dim=-1).float()
     texts = {"planted": planted, "independent": torch.from_numpy(e2e_independent_text(0))}
     st = _feat_stats(f32, f16)
     out["feat.err_over_range_bf16"] = np.array(st["err_over_range"])

@@ -25,7 +25,7 @@ def test_build_and_symbols():
     for s in hs:
         assert hasattr(l, s), f"{s} declared in tspo_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == hs, "ctypes binding and header disagree"
-    assert l.tspo_version() == 3 == _lib.ABI_VERSION
+    assert l.tspo_version() == 4 == _lib.ABI_VERSION
 
 
 def test_argument_validation_without_gpu():

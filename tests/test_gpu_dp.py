@@ -153,6 +153,87 @@ def test_gradient_accumulation_equals_concatenated_batch():
     assert abs(st["lr"] - 5e-4) < 1e-12 and abs(sch.current_lr() - 4.5e-4) < 1e-12
 
 
+@pytest.mark.parametrize("dim,heads,Tn,Gn,kn,per", [(768, 8, 512, 8, 16, 1), (D, H, 96, 4, 8, 2)], ids=["reference-1x2-D768-T512", "2x2-D64-T96"])
+def test_coalesced_micro_steps_equal_the_sequential_accumulation(dim, heads, Tn, Gn, kn, per):
+    """The reference trains with per_device_train_batch_size 1 x gradient_accumulation_steps 2 (train_deepspeed.sh:30-31) and does
+    not update the weights between the micro-steps (tspo_trainer.py:500-552): the window's prompts as ONE stacked rollout /
+    backward (`micro_steps=2`) must reproduce the sequential path - scores and Gumbel-top-k indices (IN-KERNEL Philox noise: every
+    prompt draws from the offset its own rollout() call would have used) bit for bit, log-probs and advantages bit for bit, the
+    accumulated gradient bucket within 5e-6 of its largest element (summation order of the weight-gradient reductions), and the
+    parameters after clip + AdamW; two optimizer steps, so the Philox offsets of the second window are checked too."""
+    g = torch.Generator(device=DEV).manual_seed(31)
+    if dim == D:
+        flat0 = _flat(DEV)
+    else:
+        offs = ops.flat_offsets(dim)
+        flat0 = torch.zeros(offs["__total__"][0], device=DEV)
+        for name, (off, shape) in offs.items():
+            if name.endswith(".weight"):
+                flat0[off:off + dim * dim] = torch.randn(dim * dim, generator=g, device=DEV) * 0.02
+    seq = PolicyTrainer(flat0.clone(), dim=dim, heads=heads, window_size=W, max_grad_norm=MAX_NORM, grad_accum_steps=2, seed=77)
+    coa = PolicyTrainer(flat0.clone(), dim=dim, heads=heads, window_size=W, max_grad_norm=MAX_NORM, grad_accum_steps=2, seed=77)
+    for step in range(2):
+        f = torch.randn(2 * per, Tn, dim, generator=g, device=DEV)
+        t = torch.randn(2 * per, 1, dim, generator=g, device=DEV)
+        c = ops.clip_scores(t, f)
+        rew = (torch.rand(2 * per, Gn, generator=g, device=DEV) > 0.5).float() + torch.rand(2 * per, Gn, generator=g, device=DEV)
+        outs = []
+        for m in range(2):
+            sl = slice(m * per, (m + 1) * per)
+            sc, idx, lp, ctx = seq.rollout(f[sl], t[sl], c[sl], Gn, kn, TAU)
+            st = seq.backward(ctx, f[sl], t[sl], lp, idx, rew[sl])
+            outs.append((sc, idx, lp, st["advantages"], st["loss"]))
+        sc2, idx2, lp2, ctx2 = coa.rollout(f, t, c, Gn, kn, TAU, micro_steps=2)
+        assert ctx2.micro_steps == 2 and coa._rollouts == seq._rollouts
+        st2 = coa.backward(ctx2, f, t, lp2, idx2, rew)
+        assert coa.at_boundary() and seq.at_boundary()
+        for j, (a, b) in enumerate(zip((sc2, idx2, lp2, st2["advantages"], st2["loss"]), zip(*outs))):
+            assert torch.equal(a, torch.cat(list(b))), ("scores", "indices", "logp", "advantages", "loss")[j]
+        assert not torch.equal(idx2[0], idx2[per]), "the two micro-steps drew the same noise"
+        n = seq.n_train
+        gs, gc = seq.grad[:n], coa.grad[:n]
+        assert (gs - gc).abs().max().item() <= 5e-6 * gs.abs().max().item(), (gs - gc).abs().max().item() / gs.abs().max().item()
+        seq.optimizer_step()
+        coa.optimizer_step()
+        np.testing.assert_allclose(coa.flat[:n].cpu().numpy(), seq.flat[:n].cpu().numpy(), rtol=1e-5, atol=5e-4 * 1e-3)
+        # the second window checks the Philox offsets bit for bit again: start it from identical parameters / moments (the
+        # gradients above agree to rounding, not bitwise)
+        coa.flat.copy_(seq.flat); coa.m.copy_(seq.m); coa.v.copy_(seq.v)
+    # misuse: a window that does not fit, a batch that does not split
+    with pytest.raises(ValueError):
+        coa.rollout(f, t, c, Gn, kn, TAU, micro_steps=3)
+    one = PolicyTrainer(flat0.clone(), dim=dim, heads=heads, window_size=W, grad_accum_steps=1)
+    with pytest.raises(ValueError):
+        one.rollout(f, t, c, Gn, kn, TAU, micro_steps=2)
+
+
+def test_backward_sorts_foreign_or_edited_index_tensors():
+    """the 'is this the tensor the rollout emitted' check is identity + version, not an address - an in-place edit of
+    the emitted tensor (idx.copy_(reordered)) or a different tensor at a recycled address must still be sorted on the device."""
+    f, t, c, noise, rew = (x.to(DEV) for x in _batch(0))
+    ref = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W, max_grad_norm=MAX_NORM)
+    sc, idx, lp, ctx = ref.rollout(f, t, c, G, K, TAU, noise=noise)
+    ref.backward(ctx, f, t, lp, idx, rew)
+    for how in ("inplace", "recycled"):
+        tr = PolicyTrainer(_flat(DEV), dim=D, heads=H, window_size=W, max_grad_norm=MAX_NORM)
+        sc, idx, lp, ctx = tr.rollout(f, t, c, G, K, TAU, noise=noise)
+        rev = idx.flip(-1).clone()                         # descending lists: the same SETS, not ascending
+        if how == "inplace":
+            idx.copy_(rev)                                 # same tensor object, same address, new version
+            use = idx
+        else:
+            ptr = idx.data_ptr()
+            del idx
+            ctx.idx = None                                 # drop the pin so the allocator may hand the block out again
+            use = torch.empty_like(rev)
+            use.copy_(rev)
+            if use.data_ptr() != ptr:
+                pass                                       # (allocator chose another block: the test still checks the foreign-tensor path)
+        tr.backward(ctx, f, t, lp, use, rew)
+        n = tr.n_train
+        assert torch.equal(tr.grad[:n], ref.grad[:n]), how
+
+
 def test_fused_gradient_norm_equals_the_separate_pass(monkeypatch):
     """Single rank, no accumulation: the backward's split reduction also leaves the bucket's sum of squares
     (tspo_policy_backward_ex -> tspo_adamw_clip_step_ex, one launch less, no second pass over the gradient).  Same

@@ -328,8 +328,10 @@ def test_bench_line_explains_itself_and_times_the_dp_path():
     assert by is not None and dp["launches_per_optimizer_step"] == round(sum(by.values()))
     # (a one-rank RCCL all-reduce is a device copy, which the launch count leaves out like every memcpy; `comm` below shows the
     # group the step's reduce_fn ran on)
-    assert by.get("adamw_clip_kernel") == 1.0 and by.get("gumbel_topk_kernel") == 2.0       # one update, two micro-steps
-    assert dp["launches_per_optimizer_step"] <= 28          # 2 x 13 micro-step kernels (final-tile weight gradients: no reduction launch, the second micro-batch is added in place) + norm + AdamW
+    assert by.get("adamw_clip_kernel") == 1.0 and by.get("gumbel_topk_kernel") == 1.0       # one update, ONE sampler launch for both micro-steps
+    assert dp["launches_per_optimizer_step"] <= 16          # round 5: the window's two prompts as one stacked rollout / backward (sequential: 28)
+    assert dp["sequential"]["launches_per_optimizer_step"] <= 28 and dp["sequential"]["rollouts_per_s"] < dp["rollouts_per_s"]
+    assert isinstance(dp["runtime_copies_per_optimizer_step"], dict) and 0 < dp["roofline"]["frac"] < 1
     comm = line["comm"]
     assert comm["world"] == 1 and comm["backend"] == "nccl" and comm["sum_correct"] and comm["distinct_devices"] == 1
     assert comm["ranks"][0]["pci"] == roof["gpu_state"]["pci"]

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(PKG, "libtspo_hip.so")
 
 TSPO_F32, TSPO_BF16, TSPO_F16, TSPO_U8 = 0, 1, 2, 3
 TSPO_CLIP_NO_LN_FOLD, TSPO_CLIP_PRUNE_LAST = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = C.c_void_p
 _i = C.c_int
@@ -51,6 +51,7 @@ SIGNATURES = {
     "tspo_topk_sorted": (_i, [_p, _i, _i, _i, _p, _p]),
     "tspo_binmax": (_i, [_p, _i, _i, _i, _p, _p]),
     "tspo_gumbel_topk": (_i, [_p, _p, _u64, _u64, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "tspo_gumbel_topk_ex": (_i, [_p, _p, _u64, _u64, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _i]),
     "tspo_grpo_advantage": (_i, [_p, _i, _i, _f, _p, _p]),
     "tspo_pg_grad_logits": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p]),
     "tspo_grpo_pg_grad": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p]),

@@ -109,6 +109,11 @@ __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], co
     // per-slice (mean, centred sum of squares): two passes over the 16 stored values of this lane (packed adds / fmas),
     // so the later combination of the N/64 slices (Chan et al.) is as robust as a two-pass LayerNorm.  The 4-lane sums
     // use v_permlane16/32_swap: no LDS round trip (ds_bpermute) in the middle of the epilogue.
+    // Contraction is OFF in this block and every fused multiply-add is spelled out: this code is instantiated several times
+    // per kernel (two slices of the whole-tile epilogue, the 64x64 remainder sub-tiles) and hipcc's choice of what to fuse differed
+    // between the copies - 1 ulp in the sum of squares of odd slices (round 5, found by the frame-permutation test) - which
+    // made a frame's features depend on WHERE in the batch it sat.  Now every copy performs the same operations.
+#pragma clang fp contract(off)
     auto sum4 = [](float x) {
       const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
       x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
@@ -116,15 +121,15 @@ __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], co
       return __uint_as_float(b[0]) + __uint_as_float(b[1]);
     };
     f32x2_t s2 = (st_lo[0] + st_hi[0]) + (st_lo[1] + st_hi[1]);
-    s2 += (st_lo[2] + st_hi[2]) + (st_lo[3] + st_hi[3]);
+    s2 = s2 + ((st_lo[2] + st_hi[2]) + (st_lo[3] + st_hi[3]));
     const float smean = sum4(s2[0] + s2[1]) * (1.0f / 64.0f);
     const f32x2_t mm = {smean, smean};
     f32x2_t q2 = {0.f, 0.f};
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const f32x2_t d0 = st_lo[ni] - mm, d1 = st_hi[ni] - mm;
-      q2 = d0 * d0 + q2;
-      q2 = d1 * d1 + q2;
+      q2 = __builtin_elementwise_fma(d0, d0, q2);
+      q2 = __builtin_elementwise_fma(d1, d1, q2);
     }
     const float ssq = sum4(q2[0] + q2[1]);
     const int cslice = (n0 >> 6) + wn;

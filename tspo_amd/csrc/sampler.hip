@@ -242,9 +242,9 @@ extern "C" int tspo_binmax(const float* scores, int B, int T, int k, int64_t* id
 // selection's passes, like the global-key path of topk_sorted_kernel; results are identical to the LDS-resident form.
 template <bool LONG>
 __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
-    const float* __restrict__ logits, const float* __restrict__ noise, uint32_t key0, uint32_t key1, uint32_t off_lo,
-    int G, int T, int k, float tau, int64_t* __restrict__ idx, float* __restrict__ logp, float* __restrict__ probs,
-    float* __restrict__ noise_out) {
+    const float* __restrict__ logits, const float* __restrict__ noise, uint32_t key0, uint32_t seed_hi, uint64_t offset,
+    int per_offset, int G, int T, int k, float tau, int64_t* __restrict__ idx, float* __restrict__ logp,
+    float* __restrict__ probs, float* __restrict__ noise_out) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];  // T keys, then T floats (z) when probs wanted
   __shared__ SelShared sh;
   __shared__ float red[32];
@@ -252,8 +252,13 @@ __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
   const float* l = logits + (size_t)b * T;
   const size_t row = ((size_t)b * G + g) * T;
   float* zbuf = reinterpret_cast<float*>(lds_keys + (LONG ? 0 : T));
+  // per_offset = p > 0: prompts come in groups of p that would have been separate calls (micro-steps of one optimizer step):
+  // prompt b draws what prompt b % p of a call with offset + b / p draws
+  const uint64_t off = per_offset > 0 ? offset + (uint64_t)(b / per_offset) : offset;
+  const uint32_t cb = (uint32_t)(per_offset > 0 ? b % per_offset : b);
+  const uint32_t key1 = seed_hi ^ (uint32_t)(off >> 32), off_lo = (uint32_t)off;
   auto gnoise = [&](int t) {
-    return noise ? noise[row + t] : gumbel_from_bits(philox_x0((uint32_t)t, (uint32_t)g, (uint32_t)b, off_lo, key0, key1));
+    return noise ? noise[row + t] : gumbel_from_bits(philox_x0((uint32_t)t, (uint32_t)g, cb, off_lo, key0, key1));
   };
   auto zf = [&](int t) { return (l[t] + gnoise(t)) / tau; };
   float zmax = -INFINITY, lmax = -INFINITY;
@@ -306,25 +311,32 @@ __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
   }
 }
 
-extern "C" int tspo_gumbel_topk(const float* logits, const float* noise, uint64_t seed, uint64_t offset, int B, int G,
-                                int T, int k, float tau, int64_t* idx, float* logp, float* probs, float* noise_out,
-                                tspo_stream_t stream) {
+extern "C" int tspo_gumbel_topk_ex(const float* logits, const float* noise, uint64_t seed, uint64_t offset, int B, int G,
+                                   int T, int k, float tau, int64_t* idx, float* logp, float* probs, float* noise_out,
+                                   tspo_stream_t stream, int prompts_per_offset) {
   TSPO_REQUIRE(logits && idx, "gumbel_topk: null pointer");
   TSPO_REQUIRE(B >= 0 && G >= 1 && T >= 1 && k >= 1, "gumbel_topk: bad dims B=%d G=%d T=%d k=%d", B, G, T, k);
   TSPO_REQUIRE(k <= T, "gumbel_topk: selected index k out of range (k=%d > T=%d)", k, T);
   TSPO_REQUIRE(tau > 0.f, "gumbel_topk: tau must be > 0");
+  TSPO_REQUIRE(prompts_per_offset >= 0 && (prompts_per_offset == 0 || B % prompts_per_offset == 0),
+               "gumbel_topk: prompts_per_offset=%d does not divide B=%d", prompts_per_offset, B);
   if (B == 0) return TSPO_OK;
-  const uint32_t key0 = (uint32_t)(seed & 0xFFFFFFFFu);
-  const uint32_t key1 = (uint32_t)(((seed >> 32) ^ (offset >> 32)) & 0xFFFFFFFFu);
+  const uint32_t key0 = (uint32_t)(seed & 0xFFFFFFFFu), seed_hi = (uint32_t)(seed >> 32);
   if (T <= SEL_LDS_KEYS) {
     const size_t lds = (size_t)T * 4 * (probs ? 2 : 1);
     hipLaunchKernelGGL(gumbel_topk_kernel<false>, dim3(G, B), dim3(SEL_THREADS), lds, (hipStream_t)stream, logits, noise, key0,
-                       key1, (uint32_t)(offset & 0xFFFFFFFFu), G, T, k, tau, idx, logp, probs, noise_out);
+                       seed_hi, offset, prompts_per_offset, G, T, k, tau, idx, logp, probs, noise_out);
   } else {
     hipLaunchKernelGGL(gumbel_topk_kernel<true>, dim3(G, B), dim3(SEL_THREADS), 0, (hipStream_t)stream, logits, noise, key0,
-                       key1, (uint32_t)(offset & 0xFFFFFFFFu), G, T, k, tau, idx, logp, probs, noise_out);
+                       seed_hi, offset, prompts_per_offset, G, T, k, tau, idx, logp, probs, noise_out);
   }
   return tspo::check_launch("gumbel_topk");
+}
+
+extern "C" int tspo_gumbel_topk(const float* logits, const float* noise, uint64_t seed, uint64_t offset, int B, int G,
+                                int T, int k, float tau, int64_t* idx, float* logp, float* probs, float* noise_out,
+                                tspo_stream_t stream) {
+  return tspo_gumbel_topk_ex(logits, noise, seed, offset, B, G, T, k, tau, idx, logp, probs, noise_out, stream, 0);
 }
 
 // ---------------------------------------------------------------------------

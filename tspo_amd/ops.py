@@ -83,9 +83,11 @@ def binmax(scores: torch.Tensor, k: int) -> torch.Tensor:
 
 
 def gumbel_topk(logits: torch.Tensor, k: int, G: int = 1, noise: Optional[torch.Tensor] = None, seed: int = 0,
-                offset: int = 0, tau: float = 1.0, want_probs: bool = False, want_noise: bool = False):
+                offset: int = 0, tau: float = 1.0, want_probs: bool = False, want_noise: bool = False,
+                prompts_per_offset: int = 0):
     """logits [B,T]; noise [B,G,T] or None (in-kernel Philox).  Returns dict with idx [B,G,k], logp [B,T]
-    and optionally probs / noise [B,G,T]."""
+    and optionally probs / noise [B,G,T].  prompts_per_offset = p > 0: the batch holds B / p micro-steps of p prompts;
+    group j draws what a separate call with offset + j would (coalesced micro-steps, bitwise the sequential rollouts)."""
     _need_gpu(logits, noise)
     l = _f32c(logits)
     B, T = l.shape
@@ -101,8 +103,11 @@ def gumbel_topk(logits: torch.Tensor, k: int, G: int = 1, noise: Optional[torch.
     logp = torch.empty((B, T), dtype=torch.float32, device=dev)
     probs = torch.empty((B, G, T), dtype=torch.float32, device=dev) if want_probs else None
     nout = torch.empty((B, G, T), dtype=torch.float32, device=dev) if want_noise else None
-    check(_lib.lib().tspo_gumbel_topk(_ptr(l), _ptr(n), seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), B, G, T, int(k),
-                                      float(tau), _ptr(idx), _ptr(logp), _ptr(probs), _ptr(nout), _stream()),
+    if prompts_per_offset < 0 or (prompts_per_offset and B % prompts_per_offset):
+        raise ValueError(f"prompts_per_offset={prompts_per_offset} does not divide B={B}")
+    check(_lib.lib().tspo_gumbel_topk_ex(_ptr(l), _ptr(n), seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), B, G, T, int(k),
+                                         float(tau), _ptr(idx), _ptr(logp), _ptr(probs), _ptr(nout), _stream(),
+                                         int(prompts_per_offset)),
           "tspo_gumbel_topk")
     return {"idx": idx, "logp": logp, "probs": probs, "noise": nout}
 

@@ -68,12 +68,15 @@ class RolloutContext:
     """What `PolicyTrainer.rollout` saved for the matching backward: the selector workspace holding the activations
     of THAT forward, the shapes / temperature they belong to, and the parameter version they were computed with.
     Opaque to callers; `PolicyTrainer.backward` validates and consumes it (a context is good for one backward)."""
-    __slots__ = ("ws", "shape", "M", "tau", "param_version", "serial", "consumed", "owner", "idx_ptr")
+    __slots__ = ("ws", "shape", "M", "tau", "param_version", "serial", "consumed", "owner", "idx", "idx_version", "micro_steps")
 
-    def __init__(self, ws, shape, M, tau, param_version, serial, owner, idx_ptr=0):
+    def __init__(self, ws, shape, M, tau, param_version, serial, owner, idx=None, micro_steps=1):
         self.ws, self.shape, self.M, self.tau = ws, tuple(shape), M, float(tau)
         self.param_version, self.serial, self.consumed, self.owner = param_version, serial, False, owner
-        self.idx_ptr = idx_ptr              # the index tensor this rollout emitted (ascending by construction)
+        # the index tensor this rollout emitted (ascending by construction) - the TENSOR, which also pins its storage, and its
+        # version counter: an address can be recycled by the allocator and `idx.copy_(...)` keeps it, identity + version cannot lie
+        self.idx, self.idx_version = idx, (idx._version if idx is not None else -1)
+        self.micro_steps = int(micro_steps)  # how many micro-steps of the accumulation window this batch holds
 
 
 class PolicyTrainer:
@@ -86,6 +89,14 @@ class PolicyTrainer:
     and, on the accumulation boundary only, `optimizer_step()`: ONE all-reduce of the bucket
     (`reduce_fn`, default tspo_amd.dist.allreduce_bucket_ = RCCL over xGMI), clip-norm of the mean, fused AdamW.
     `step()` / `update()` wrap these for the common one-micro-batch case.
+
+    Coalesced micro-steps (round 5).  The micro-steps of one optimizer step see the same weights (no update between them,
+    tspo_trainer.py:500-552), so their policy math is one batch: `rollout(..., micro_steps=n)` takes the prompts of n micro-steps
+    stacked along B ([n * B_micro, T, D]; equal T / k), draws every group's Gumbel noise from the Philox offset its own
+    `rollout()` call would have used (indices bitwise those of the sequential path) and the matching `backward()` counts as n
+    micro-steps - one forward, one sampler launch, one backward instead of n.  The reference's configuration
+    (per_device_train_batch_size 1 x gradient_accumulation_steps 2, train_deepspeed.sh:30-31): 15 launches per optimizer step
+    instead of 28.  `tspo_amd.train` does this whenever the micro-batches of a window stack.
     """
 
     def __init__(self, flat: torch.Tensor, dim: int = 768, heads: int = 8, window_size: int = 12,
@@ -147,10 +158,15 @@ class PolicyTrainer:
         return (self.seed + 0x9E3779B97F4A7C15 * self.rank()) & (2 ** 64 - 1)
 
     # ---- micro-step ---------------------------------------------------------------------------------------
-    def rollout(self, feats, txt, clip, G: int, k: int, tau: float, noise=None):
+    def rollout(self, feats, txt, clip, G: int, k: int, tau: float, noise=None, micro_steps: int = 1):
         """scores once, G Gumbel-top-k rollouts per prompt in one launch (tspo_trainer.py:508-537).
-        Returns (scores [B,T], idx [B,G,k], logp [B,T], ctx) - pass `ctx` to the matching backward()."""
+        Returns (scores [B,T], idx [B,G,k], logp [B,T], ctx) - pass `ctx` to the matching backward().
+        micro_steps = n > 1: the batch stacks the prompts of n micro-steps of this accumulation window (class docstring)."""
         B, T, D = feats.shape
+        n = int(micro_steps)
+        if n < 1 or B % n or (n > 1 and self._micro + n > self.grad_accum_steps):
+            raise ValueError(f"rollout(micro_steps={n}): B={B} must be a multiple of it and {self._micro} + {n} micro-steps must fit "
+                             f"the accumulation window of {self.grad_accum_steps}")
         need = ops._lib.lib().tspo_selector_workspace_bytes(B, T, D, self.heads, txt.shape[1], self.window)
         ws = None
         for i, cand in enumerate(self._ws_pool):
@@ -161,9 +177,10 @@ class PolicyTrainer:
             ws = torch.empty((need,), dtype=torch.uint8, device=feats.device)
         scores, _, _ = ops.selector_forward(self.flat, feats, txt, clip, self.heads, self.window, tau, want_attn=False,
                                             ws=ws, precision=self.gemm_precision)
-        out = ops.gumbel_topk(scores, k, G, noise=noise, seed=self._rank_seed(), offset=self._rollouts)
-        ctx = RolloutContext(ws, (B, T, D), txt.shape[1], tau, self._param_version, self._rollouts, self, out["idx"].data_ptr())
-        self._rollouts += 1
+        out = ops.gumbel_topk(scores, k, G, noise=noise, seed=self._rank_seed(), offset=self._rollouts,
+                              prompts_per_offset=B // n if n > 1 else 0)
+        ctx = RolloutContext(ws, (B, T, D), txt.shape[1], tau, self._param_version, self._rollouts, self, out["idx"], n)
+        self._rollouts += n
         return scores, out["idx"], out["logp"], ctx
 
     def backward(self, ctx: RolloutContext, feats, txt, logp, idx, rewards) -> Dict[str, torch.Tensor]:
@@ -178,9 +195,10 @@ class PolicyTrainer:
         if tuple(feats.shape) != ctx.shape or txt.shape[1] != ctx.M:
             raise ValueError(f"backward(): feats {tuple(feats.shape)} / txt M={txt.shape[1]} do not match the rollout "
                              f"this context belongs to ({ctx.shape}, M={ctx.M})")
-        if self._micro >= self.grad_accum_steps:
+        n = ctx.micro_steps
+        if self._micro + n > self.grad_accum_steps:
             raise RuntimeError("gradient accumulation boundary reached: call optimizer_step() before another backward()")
-        if idx.data_ptr() != ctx.idx_ptr:
+        if not (idx is ctx.idx and idx._version == ctx.idx_version):
             # an index tensor that is not the one this rollout emitted (e.g. a reference-style `ts_ids` in selection order): the
             # gradient kernels find a frame's rollouts by binary search in ascending lists, so sort each rollout's list on
             # the device (membership - all the policy gradient uses - does not depend on the order; no host sync)
@@ -189,11 +207,12 @@ class PolicyTrainer:
         # the second.. micro-step ADDS its gradient into the bucket inside the backward's own kernels (TSPO_SEL_ACCUMULATE): no
         # scratch bucket, no add pass
         target, acc = self.grad, self._micro > 0
-        scale = 1.0 / (B * self.grad_accum_steps)
+        scale = 1.0 / ((B // n) * self.grad_accum_steps)      # every micro-step weighs 1 / accum, its prompts 1 / B_micro
         self._norm_np = 0
-        # single rank, no accumulation, default exchange: nothing touches the bucket between this backward and AdamW, so the
-        # backward's last kernel (the split reduction that writes the bucket) also leaves its sum of squares
-        fuse_norm = (self.grad_accum_steps == 1 and self._default_reduce and self.reduce_fn is self._reduce_default
+        # single rank, the whole accumulation window in this one backward, default exchange: nothing touches the bucket between
+        # this backward and AdamW, so the backward's last kernel (the split reduction that writes the bucket) also leaves its
+        # sum of squares
+        fuse_norm = (self.grad_accum_steps == n and self._default_reduce and self.reduce_fn is self._reduce_default
                      and self.world() == 1 and not self._dist_initialised())
         if idx.shape[1] <= 64 and fuse_norm:
             adv, loss, self._norm_np = ops.policy_backward(self.flat, target, feats, txt, rewards, logp, idx, self.heads,
@@ -207,10 +226,10 @@ class PolicyTrainer:
             adv, dlog, loss = ops.grpo_pg_grad(rewards, logp, idx, scale=scale)
             ops.selector_backward(self.flat, target, feats, txt, dlog, self.heads, self.window, ctx.tau, ctx.ws,
                                   precision=self.gemm_precision, accumulate=acc)
-        self._micro += 1
+        self._micro += n
         ctx.consumed = True
         self._ws_pool.append(ctx.ws)
-        ctx.ws = None
+        ctx.ws, ctx.idx = None, None
         # `loss` is the kernels' UNSCALED per-prompt -sum(adv*...)/G (only dL/dscores carries `scale`): callers average it
         # over micro-steps themselves (train.py), so it is returned as is whatever grad_accum_steps is
         return {"loss": loss, "advantages": adv}
@@ -252,8 +271,8 @@ class PolicyTrainer:
         return stats
 
     def step(self, feats, txt, clip, reward_fn: Callable[[torch.Tensor], torch.Tensor], G: int, k: int, tau: float,
-             noise=None, lr: Optional[float] = None):
-        scores, idx, logp, ctx = self.rollout(feats, txt, clip, G, k, tau, noise)
+             noise=None, lr: Optional[float] = None, micro_steps: int = 1):
+        scores, idx, logp, ctx = self.rollout(feats, txt, clip, G, k, tau, noise, micro_steps=micro_steps)
         rewards = reward_fn(idx)                      # [B,G] - the frozen video-LLM pass lives here (stock PyTorch)
         stats = self.update(ctx, feats, txt, logp, idx, rewards, lr)
         stats.update(scores=scores, idx=idx, rewards=rewards)

@@ -60,6 +60,7 @@ class TrainConfig:
     dim: int = 768
     heads: int = 8
     gemm_precision: str = "fp32"
+    coalesce_micro_steps: bool = True      # run the micro-steps of an optimizer step as one stacked batch when their shapes allow
 
 
 class Batch:
@@ -118,6 +119,17 @@ class FeatureCacheDataset:
                 mask = stat.get("mask", torch.ones(img.shape[1], dtype=torch.bool)).to(self.dev).reshape(1, -1)
                 yield Batch(img, txt, clip, mask, stat.get("type", "specific"), {"path": path})
             pos = 0
+
+
+def _stackable(window: List[Batch]) -> bool:
+    a = window[0]
+    return len(window) > 1 and all(b.feats.shape == a.feats.shape and b.txt.shape == a.txt.shape and b.mask.shape == a.mask.shape
+                                   and b.item_type == a.item_type for b in window[1:])
+
+
+def _stack(window: List[Batch]) -> Batch:
+    return Batch(torch.cat([b.feats for b in window]), torch.cat([b.txt for b in window]), torch.cat([b.clip for b in window]),
+                 torch.cat([b.mask for b in window]), window[0].item_type, [b.meta for b in window])
 
 
 def mask_reward_model(idx: torch.Tensor, batch: Batch) -> torch.Tensor:
@@ -187,27 +199,33 @@ def train(cfg: TrainConfig, data, reward_model: Callable[[torch.Tensor, Batch], 
     t0 = time.perf_counter()
     for step in range(start, cfg.max_steps):
         tau = annealed_tau(cfg.score_tau, step, cfg.max_steps)
-        acc_m: Dict[str, float] = {k: 0.0 for k in tdist.METRIC_KEYS}
-        acc_r = [0.0] * len(REWARD_NAMES)
-        for _micro in range(cfg.gradient_accumulation_steps):
-            b = next(it)
+        window = [next(it) for _ in range(cfg.gradient_accumulation_steps)]
+        # The micro-steps of one optimizer step see the same weights (tspo_trainer.py:500-552: no update between them), so when
+        # their batches stack - same T, text rows, item type (hence k) - they run as ONE rollout / backward of the stacked batch
+        # (PolicyTrainer, "coalesced micro-steps": same Philox draws per prompt as the sequential path, 15 launches instead of 28
+        # for the reference's 1 x 2 configuration).  Videos of different length (feature caches) keep one micro-step each.
+        groups = [window] if cfg.coalesce_micro_steps and _stackable(window) else [[b] for b in window]
+        acc = torch.zeros(len(tdist.METRIC_KEYS) + len(REWARD_NAMES), dtype=torch.float32, device=dev)   # metrics stay on the device
+        for grp in groups:
+            b = grp[0] if len(grp) == 1 else _stack(grp)
             k = rewards.training_sample_len(cfg.training_sample_len, b.item_type)
-            scores, idx, logp, ctx = trainer.rollout(b.feats, b.txt, b.clip, cfg.num_generations, k, tau)
+            scores, idx, logp, ctx = trainer.rollout(b.feats, b.txt, b.clip, cfg.num_generations, k, tau, micro_steps=len(grp))
             rpf = reward_model(idx, b)                                           # [B, G, F]   (frozen video-LLM plug-in)
             B, G, F = rpf.shape
             rew = rewards.combine_rewards(rpf.reshape(B * G, F), b.item_type).reshape(B, G)
             st = trainer.backward(ctx, b.feats, b.txt, logp, idx, rew)
-            w = 1.0 / cfg.gradient_accumulation_steps
-            acc_m["ts_length"] += w * k
-            acc_m["reward"] += w * rew.mean().item()
-            acc_m["advantages"] += w * st["advantages"].mean().item()
-            acc_m["reward_mean"] += w * rew.mean(dim=1).mean().item()
-            acc_m["reward_std"] += w * rew.std(dim=1).mean().item()
-            for j in range(len(REWARD_NAMES)):
-                acc_r[j] += w * rpf[..., j].mean().item()
-            acc_m["loss"] += w * st["loss"].mean().item()
+            w = len(grp) / cfg.gradient_accumulation_steps
+            vals = {"ts_length": torch.tensor(float(k), device=dev), "reward": rew.mean(), "advantages": st["advantages"].mean(),
+                    "reward_mean": rew.mean(dim=1).mean(), "reward_std": rew.std(dim=1).mean(), "loss": st["loss"].mean()}
+            for j, key in enumerate(tdist.METRIC_KEYS):
+                if key in vals:
+                    acc[j] += w * vals[key]
+            acc[len(tdist.METRIC_KEYS):] += w * rpf.reshape(B * G, F).mean(dim=0)
         ost = trainer.optimizer_step()
         if (step + 1) % cfg.logging_steps == 0:
+            host = acc.tolist()                                                  # the step's ONE device -> host transfer
+            acc_m = dict(zip(tdist.METRIC_KEYS, host))
+            acc_r = host[len(tdist.METRIC_KEYS):]
             m = tdist.reduce_metrics(tdist.pack_metrics(acc_m, acc_r), len(REWARD_NAMES), REWARD_NAMES)
             m.update(step=step + 1, learning_rate=ost["lr"], score_tau=tau,
                      grad_norm=float(ost["grad_norm_scale"][0]) / ost["world"], elapsed_s=round(time.perf_counter() - t0, 3))
@@ -242,7 +260,10 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=0, help="ranks to run; without a launcher (no WORLD_SIZE) the driver spawns them itself")
     ap.add_argument("--no-resume", action="store_true")
     for name, val in asdict(TrainConfig()).items():
-        ap.add_argument("--" + name.replace("_", "-"), type=type(val), default=val)
+        if isinstance(val, bool):
+            ap.add_argument("--" + name.replace("_", "-"), action=argparse.BooleanOptionalAction, default=val)
+        else:
+            ap.add_argument("--" + name.replace("_", "-"), type=type(val), default=val)
     a = ap.parse_args(argv)
     if a.gpus > 1 and not tdist.launched_by_torchrun():
         import sys
