@@ -476,7 +476,10 @@ def main():
         import tempfile
         os.environ["NCCL_DEBUG"] = "INFO"
         os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
-        os.environ["NCCL_DEBUG_FILE"] = os.path.join(tempfile.gettempdir(), f"tspo_rccl_{os.getpid()}_%h_%p.log")
+        # (a directory of this launch's own - every rank of a torchrun job gets its own - removed again once the summary is taken;
+        #  RCCL writes its INIT / GRAPH / TUNING lines at communicator creation, not during the timed collectives)
+        os.environ["TSPO_RCCL_LOG_DIR"] = tempfile.mkdtemp(prefix="tspo_rccl_")
+        os.environ["NCCL_DEBUG_FILE"] = os.path.join(os.environ["TSPO_RCCL_LOG_DIR"], "rccl_%h_%p.log")
     from tspo_amd import dist as tdist
     if a.gpus > 1 and not tdist.launched_by_torchrun():
         # bare `python bench.py --gpus N`: become the launcher - one rank per GPU, like torch.distributed.run would
@@ -526,12 +529,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup, per_step=None):
+    def timed(fn, steps, warmup, per_step=None, after_warmup=None, per_rank=None):
         """`steps` calls of fn between two barriers; per_step (a list) additionally receives every step's duration from HIP
-        events recorded on the launch stream inside the same region (no extra synchronisation)."""
+        events recorded on the launch stream inside the same region (no extra synchronisation).  after_warmup() runs behind the
+        first barrier (the clock / power sampler starts there: warm-up and barrier time stay out of its averages, ADVICE r4);
+        per_rank (a list) receives EVERY rank's own wall time of the region, so a slow rank shows in the first N > 1 record."""
         for _ in range(warmup):
             fn()
         barrier()
+        if after_warmup is not None:
+            after_warmup()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
         t0 = time.perf_counter()
         for i in range(steps):
@@ -544,6 +551,13 @@ def main():
         dt_ = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         if evs:
             per_step.extend(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        if per_rank is not None:
+            if world > 1:
+                allt = [torch.zeros_like(dt_) for _ in range(world)]
+                dist.all_gather(allt, dt_)
+                per_rank.extend(float(x.item()) for x in allt)
+            else:
+                per_rank.append(float(dt_.item()))
         if world > 1:
             dist.all_reduce(dt_, op=dist.ReduceOp.MAX)
         return dt_.item()
@@ -554,10 +568,12 @@ def main():
     def score_step():
         out["idx"], out["scores"], _ = scorer(pixels, txt, k)
 
-    step_ms = []
+    step_ms, rank_sec = [], []
     sampler = GpuSampler(dev)
-    with sampler:
-        sec = timed(score_step, a.steps, a.warmup, per_step=step_ms)
+    try:
+        sec = timed(score_step, a.steps, a.warmup, per_step=step_ms, after_warmup=sampler.__enter__, per_rank=rank_sec)
+    finally:
+        sampler.__exit__(None, None, None)
     gpu_state = sampler.summary()
     frames = B * T * world * a.steps
     fps = frames / sec
@@ -693,6 +709,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec / a.steps * 1e3, 3),
             "ms_per_step_min": round(min(step_ms), 3), "ms_per_step_median": round(sorted(step_ms)[len(step_ms) // 2], 3),
             "ms_per_step_max": round(max(step_ms), 3),
+            "ms_per_step_by_rank": [round(x / a.steps * 1e3, 3) for x in rank_sec],     # each rank's own clock over the timed region
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: TSPO-0.4B frame selection (CLIP-L/14 encode + scoring head + top-k)",
                        "frames_per_video": T, "videos_per_gpu_per_step": B, "topk": k, "window": 12, "tau": 0.025,
@@ -755,6 +772,9 @@ def main():
     if world > 1:
         dist.barrier()   # rank 0 is still profiling / printing while the others are done: leave together
         dist.destroy_process_group()
+    if os.environ.get("TSPO_RCCL_LOG_DIR"):      # this process's RCCL debug files (summarised into `comm` above)
+        import shutil
+        shutil.rmtree(os.environ["TSPO_RCCL_LOG_DIR"], ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -359,10 +359,11 @@ int tspo_clip_scores(const float* txt, const float* feat, int B, int T, int D, i
 /* Generic bf16 MFMA GEMM exposed for tests / micro-benchmarks:
  * C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, f32 accumulate, out bf16 or f32.
  * K % 64 == 0.  act (bits 0-7): 0 none, 1 quick_gelu.  residual (bf16 [M,N], nullable) is added.
- * Bits 8+ of `act` choose the kernel: 0 = automatic (what the encoder uses), 1 = small-problem 128x128 kernel,
- * 6 = 8-wave LDS-DMA ring kernel, 82 = 4-wave AGPR kernel (K % 128 == 0).  Every choice computes the same result
- * (bit-identical between 6 and 82); other values exist only in a -DTSPO_DEV_HOOKS build (A/B variants, ablations)
- * and are rejected with TSPO_EINVAL by the shipped library.                                                   */
+ * Bits 8+ of `act` choose the kernel: 0 = automatic (what the encoder uses: 77 for big shapes, else 1), 1 = small-problem
+ * 128x128 kernel, 77 = persistent 256x256 kernel with LDS-DMA operands (whole rounds of whole tiles + the 64x64 remainder
+ * phase), 83 = the same kernel with the remainder phase off (a partial last round of whole tiles; bit-identical with 77).
+ * Every choice computes the same result.  Other values (67-76 schedule A/Bs and probes, 82 = the register-staged kernel of
+ * rounds 2-3) exist only in a `python -m tspo_amd.build --dev` library and are rejected with TSPO_EINVAL by the shipped one. */
 int tspo_gemm_bf16(const void* A, const void* W, const float* bias, const void* residual,
                    void* C, int out_dtype, int M, int N, int K, int act, tspo_stream_t stream);
 

@@ -88,6 +88,21 @@ def e2e_video(n, needles, seed):
     return np.clip(frames + noise, 0, 255).astype(np.uint8)
 
 
+def full_video():
+    """The configs[1]-size video (FULL_T frames): the block-image shots of e2e_video, with the FULL_NEEDLES frames showing ONE
+    scene of a different kind - 4 x 4 large colour blocks instead of 16 x 16 (a wide shot among close-ups; +-6 grey levels of
+    per-pixel noise like every frame).  Among 1024 shots a scene that is just another block image is NOT separable by one text
+    direction with a margin above the encoders' bf16 noise (random-init CLIP features differ along a handful of directions) -
+    measured while building the fixture - and the point of the needles is a top-k whose gap exceeds that noise."""
+    v = e2e_video(FULL_T, [], FULL_VIDEO_SEED)
+    scene = synth.uniform_u8((3, 4, 4), FULL_VIDEO_SEED + 7).astype(np.int16)
+    img = np.repeat(np.repeat(scene, 56, axis=1), 56, axis=2)
+    noise = (synth.uniform_u8((len(FULL_NEEDLES), 3, 224, 224), FULL_VIDEO_SEED + 8).astype(np.int16) % 13) - 6
+    for i, j in enumerate(FULL_NEEDLES):
+        v[j] = np.clip(img + noise[i], 0, 255).astype(np.uint8)
+    return v
+
+
 def e2e_selector_state():
     return synth.selector_state(768, seed=5, std=0.02)
 

@@ -586,14 +586,14 @@ def gen_noise(_out):
 def gen_full1024(out):
     """BASELINE.json configs[1] at FULL size through the reference's own chain (model/temporal_agent.py:177-192: extract_feature ->
     temporal_sampling -> inference_ts; mp_tools/vlmeval/vlm/gen_id_tspo.py:55 for the bf16 production dtype): 1024 frames of the
-    end-to-end test's block video -> installed transformers CLIP-L/14 (fp32 arithmetic on the bf16-rounded parameters) -> cosine clip
+    full-size block video (tests/golden/inputs.py: full_video) -> installed transformers CLIP-L/14 (fp32 arithmetic on the bf16-rounded parameters) -> cosine clip
     score -> imported MultiModal_Align -> TSPOModel.inference_ts top-32 / top-64 / bin-max-32, for the planted-scene text (stored:
     it is built from the fp32 features) and an independent N(0,1) text; and the SAME chain in bf16, so the fixture also holds the
     reference's own score noise at this size.  A few KB of arrays -> tests/golden/full1024.npz.  ~25 min of CPU (8 threads)."""
-    from inputs import (FULL_T, FULL_NEEDLES, FULL_VIDEO_SEED, FULL_K, E2E_TAU, E2E_WINDOW, clip_l14_state, e2e_video,
-                        e2e_selector_state, e2e_independent_text)
+    from inputs import (FULL_T, FULL_NEEDLES, FULL_K, E2E_TAU, E2E_WINDOW, clip_l14_state, full_video, e2e_selector_state,
+                        e2e_independent_text)
     tspo_like = TSPOModel.inference_ts
-    u8 = e2e_video(FULL_T, FULL_NEEDLES, FULL_VIDEO_SEED)
+    u8 = full_video()
     cache = os.environ.get("TSPO_FULL1024_CACHE")       # generation convenience: the two feature matrices (25 min of CPU) kept in a scratch file
     if cache and os.path.exists(cache):
         zz = np.load(cache)
@@ -603,16 +603,8 @@ def gen_full1024(out):
         if cache:
             np.savez(cache, f32=f32.numpy(), f16=f16.numpy())
     sel = e2e_selector_state()
-    # the "question" about the planted scene.  With 1024 shots the plain difference (scene - mean frame) of the 64 / 128-frame
-    # tests no longer singles the scene out (random-init CLIP features differ along few directions: some unrelated frames point
-    # further along it than the scene does), so the query is the Fisher direction C^-1 (scene - mean) - what a text feature
-    # trained to retrieve that scene would be.  Built in float64 from the fp32 features and STORED (the GPU test reads it).
-    mu = f32.double().mean(0)
-    X = f32.double() - mu
-    Cm = X.T @ X / X.shape[0]
-    Cm = Cm + 1e-3 * Cm.diagonal().mean() * torch.eye(Cm.shape[0], dtype=torch.float64)
-    wdir = torch.linalg.solve(Cm, f32[FULL_NEEDLES].double().mean(0) - mu)
-    planted = torch.nn.functional.normalize(wdir[None], dim=-1).float()
+    # the "question" about the planted scene: what distinguishes its frames from the average frame (as in e2e_texts)
+    planted = torch.nn.functional.normalize(f32[FULL_NEEDLES].mean(0, keepdim=True) - f32.mean(0, keepdim=True), dim=-1)
     texts = {"planted": planted, "independent": torch.from_numpy(e2e_independent_text(0))}
     st = _feat_stats(f32, f16)
     out["feat.err_over_range_bf16"] = np.array(st["err_over_range"])

@@ -77,6 +77,61 @@ def test_dp2_bucket_allreduce_and_metrics():
     np.testing.assert_array_equal(res[0][2], res[1][2])               # replicas stay bit-identical
 
 
+def _worker8(rank, world, port, q):
+    """configs[3] / configs[4] as they are partitioned on the 8 GPUs of a node, with the REAL sizes: 32 prompts over 8 ranks, the
+    D = 768 bucket (2 952 960 trainable of 3 543 552 elements), a 4096-frame video sharded unevenly over the ranks."""
+    sys.path.insert(0, ROOT)
+    from tspo_amd import dist as td, ops
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    td.init_from_env("gloo")
+    n, total = ops.trainable_numel(768), ops.flat_offsets(768)["__total__"][0]
+    assert (n, total) == (2952960, 3543552)
+    shard = td.shard_prompts(32, world, rank)
+    bucket = torch.zeros(total)
+    for b in shard:                                      # a cheap per-prompt "gradient": value depends on (prompt, element)
+        bucket[:n] += (torch.arange(n, dtype=torch.float32) % 97 - 48.0) * (b + 1) * 1e-3
+    bucket[n:] = -3.0
+    assert td.allreduce_bucket_(bucket, n) == world
+    # frame-sharded apply over 4096 + 5 frames (uneven shards) with a [*, 768] feature block per frame
+    T = 4096 + 5
+    x = (torch.arange(T, dtype=torch.float32)[:, None] * 0.5 + torch.arange(8, dtype=torch.float32)[None]).contiguous()
+    y = td.sharded_apply(lambda t: t.repeat(1, 96) * 2.0, x)                   # [T, 768]
+    ok = y.shape == (T, 768) and torch.equal(y, x.repeat(1, 96) * 2.0)
+    m = td.reduce_metrics(td.pack_metrics(dict(ts_length=16, completion_length=0, reward=float(rank), advantages=0.0,
+                                               reward_mean=float(rank), reward_std=1.0, loss=-0.5 * rank), [float(rank % 2), 0.25]),
+                          2, ["accuracy_reward", "temporal_localization_reward"])
+    q.put((rank, list(shard), float(bucket[:n].double().sum()), float(bucket[n:].sum()), bucket[:64].numpy(), ok, m))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp8_real_shard_sizes():
+    """the N = 8 leg cannot run on hardware here, so its partitioning runs on CPU ranks with the real sizes: 32
+    prompts -> 4 per rank, ONE all-reduce of the 2 952 960-element fp32 bucket (sum over all 32 prompts on every rank, ffn_o tail
+    untouched, replicas bit-identical), a 4101-frame video sharded unevenly over 8 ranks and gathered back, packed metrics means."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [list(range(4 * i, 4 * i + 4)) for i in range(8)]
+    n = 2952960
+    base = (np.arange(n, dtype=np.float64) % 97 - 48.0)
+    expect_sum = float((base * 1e-3).sum() * sum(b + 1 for b in range(32)))
+    for _, _, tot, tail, head, ok, m in res:
+        assert ok
+        assert abs(tot - expect_sum) <= 1e-4 * abs(expect_sum) and tail == -3.0 * (3543552 - n)
+        np.testing.assert_array_equal(head, res[0][4])                                  # replicas bit-identical
+        assert abs(m["reward"] - 3.5) < 1e-6 and abs(m["loss"] + 1.75) < 1e-6 and abs(m["rewards/accuracy_reward"] - 0.5) < 1e-6
+    np.testing.assert_allclose(res[0][4], (base[:64] * 1e-3 * sum(b + 1 for b in range(32))).astype(np.float32), rtol=1e-5)
+
+
 def test_shard_prompts_covers_everything():
     from tspo_amd.dist import shard_prompts
     for n in (1, 4, 7, 32):

@@ -49,55 +49,70 @@ def self_spawn(n: int, argv: Sequence[str], module: "str | None" = None, timeout
     """Start `n` ranks of this program on this node without torch.distributed.run (one process per GPU; what
     `train_deepspeed.sh:14-16`'s `torchrun --nproc_per_node` does): `python <argv[0]> <argv[1:]>` (or `python -m module
     <argv[1:]>`) n times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, a free rendezvous port and
-    the dmabuf IPC mode RCCL needs.  Children inherit stdout/stderr (rank 0 prints the result line).  Returns the first
-    non-zero exit code (the other ranks are terminated by PID as soon as one rank fails), else 0."""
+    the dmabuf IPC mode RCCL needs.  Children inherit stdout (rank 0 prints the result line); their stderr is forwarded live
+    with a `[rank r]` prefix.  Returns the first non-zero exit code (the other ranks are terminated by PID as soon as one rank
+    fails - also when the launcher itself is interrupted), else 0."""
+    import collections
     import subprocess
     import sys
-    import tempfile
+    import threading
     import time
     port = free_port()
     cmd = [sys.executable] + (["-m", module] if module else [argv[0]]) + list(argv[1:])
-    procs, errs = [], []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSPO_SELF_SPAWNED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # stderr goes through a per-rank file so that a failing rank's last lines can be quoted in the launcher's own exit
-        # message (8 interleaved tracebacks on a terminal are unreadable); it is replayed to this process's stderr at the end
-        ef = tempfile.TemporaryFile(mode="w+b")
-        errs.append(ef)
-        procs.append(subprocess.Popen(cmd, env=env, stderr=ef))
-    t0, rc, failed = time.monotonic(), 0, None
-    live = list(procs)
-    while live and rc == 0:
-        for p in list(live):
-            code = p.poll()
-            if code is not None:
-                live.remove(p)
-                if code != 0 and rc == 0:
-                    rc, failed = code, procs.index(p)
-        if timeout is not None and time.monotonic() - t0 > timeout:
-            rc = 124
-        if live and rc == 0:
-            time.sleep(0.05)
-    for p in live:                      # a rank failed (or timed out): stop exactly the processes started here
-        p.terminate()
-    for p in live:
-        try:
-            p.wait(timeout=10)
-        except subprocess.TimeoutExpired:
-            p.kill()
-    tails = []
-    for r, ef in enumerate(errs):
-        ef.seek(0)
-        txt = ef.read().decode(errors="replace")
-        ef.close()
-        if txt:
-            sys.stderr.write(txt if n == 1 else "".join(f"[rank {r}] {ln}" for ln in txt.splitlines(True)))
-        tails.append(txt)
+    procs, tails, readers = [], [], []
+    out_lock = threading.Lock()
+
+    def forward(r, pipe, keep):
+        # every rank's stderr is forwarded LIVE, line by line, with a [rank r] prefix (a hung RCCL rendezvous must show its
+        # diagnostics while it hangs, ADVICE r4), and the last lines are kept for the launcher's own exit message
+        for raw in iter(pipe.readline, b""):
+            ln = raw.decode(errors="replace")
+            keep.append(ln)
+            with out_lock:
+                sys.stderr.write(ln if n == 1 else f"[rank {r}] {ln}")
+                sys.stderr.flush()
+        pipe.close()
+
+    rc, failed = 0, None
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSPO_SELF_SPAWNED="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            p = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE)
+            procs.append(p)
+            tails.append(collections.deque(maxlen=40))
+            t = threading.Thread(target=forward, args=(r, p.stderr, tails[-1]), daemon=True)
+            t.start()
+            readers.append(t)
+        t0 = time.monotonic()
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    if code != 0 and rc == 0:
+                        rc, failed = code, procs.index(p)
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                rc = 124
+            if live and rc == 0:
+                time.sleep(0.05)
+    finally:
+        # a rank failed, timed out, or the launcher itself is being interrupted: stop exactly the processes started here
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        for p in live:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for t in readers:
+            t.join(timeout=5)
     if rc != 0:
         who = f"rank {failed}" if failed is not None else f"timeout after {timeout} s"
-        tail = "".join(tails[failed].splitlines(True)[-12:]) if failed is not None else ""
+        tail = "".join(list(tails[failed])[-12:]) if failed is not None else ""
         sys.stderr.write(f"self_spawn: {who} of {n} exited with code {rc}; the other ranks were stopped.  Last lines of its stderr:\n{tail}")
     return rc
 
