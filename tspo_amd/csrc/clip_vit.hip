@@ -475,9 +475,23 @@ __device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const 
         const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = AT_MAX(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
       }
-      const float mnew = AT_MAX(mrun[n], mx * c2);
-      alpha[n] = __builtin_amdgcn_exp2f(mrun[n] - mnew);   // first block: exp2(-inf) = 0 (o and l are 0 anyway)
-      mrun[n] = mnew;
+      // Lazy rescaling (round 5): the running maximum only has to keep exp2 in range, it need not BE the maximum.  The first
+      // block sets it; a later block moves it - and pays the 10 packed multiplies on o / lsum plus one exp2 per query tile -
+      // only when one of the wave's queries has a block maximum more than 2^8 above its running one (wave-uniform branch).
+      // Otherwise P = exp2(s - m_run) <= 2^8: bf16 keeps its relative precision, the fp32 accumulators have the headroom, and the
+      // final o / l is the same quotient.  Scores within 8 (log2 units) of the first block's maximum - every block of every
+      // test so far - never rescale: -120 of ~1300 vector instructions per wave and item.
+      const float mcand = mx * c2;
+      bool moved = false;
+      if (b == b0) {
+        mrun[n] = mcand;                                   // o and l are zero: nothing to rescale
+      } else if (__builtin_amdgcn_ballot_w64(mcand > mrun[n] + 8.0f) != 0) {
+        const float mnew = AT_MAX(mrun[n], mcand);
+        alpha[n] = __builtin_amdgcn_exp2f(mrun[n] - mnew);
+        mrun[n] = mnew;
+        moved = true;
+      }
+      const float mnew = mrun[n];
       const f32x2 c2v = {c2, c2}, nm = {-mnew, -mnew};
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
@@ -493,9 +507,11 @@ __device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const 
           sc[n][j][2] = __builtin_amdgcn_exp2f(th[0]); sc[n][j][3] = __builtin_amdgcn_exp2f(th[1]);
         }
       }
-      lsum[n] *= alpha[n];
+      if (moved) {
+        lsum[n] *= alpha[n];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[n][dt] *= alpha[n];
+        for (int dt = 0; dt < 4; ++dt) o[n][dt] *= alpha[n];
+      }
     }
     // ---- O^T += V^T P^T over the 3 key chunks (32 keys) of this block ----
     const char* vb = Vt + (VROW ? b * (KT / 2) * 4096 : b * (KT / 2) * 4 * A4_VSUB);
@@ -616,8 +632,10 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
     float m1[1], l1[1];
     f32x4 o1[1][4];
     bf16x8 qf1[1][2];
-    attn257_load_q<1>(base, ld, 16, l15, q4, qf1);
-    attn257_blocks<1>(qf1, Ks, Vt, scale, wid, wid + 1, l15, q4, m1, l1, o1);
+    int l15b = l15, q4b = q4;                     // (opaque copies: the LDS offsets of this pass are recomputed from them instead of
+    asm volatile("" : "+v"(l15b), "+v"(q4b));      //  being kept alive - one of them in scratch - across the main pass: 256 VGPRs are all in use)
+    attn257_load_q<1>(base, ld, 16, l15b, q4b, qf1);
+    attn257_blocks<1>(qf1, Ks, Vt, scale, wid, wid + 1, l15b, q4b, m1, l1, o1);
     if (l15 == 0) {
       float* pw = part + wid * 68;
 #pragma unroll
