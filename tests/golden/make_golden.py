@@ -487,8 +487,13 @@ def _both(model, px, progress=None):
 
 def _feat_stats(f32, f16):
     cos = torch.nn.functional.cosine_similarity(f32, f16, dim=-1)
-    return {"err_over_range": float((f16 - f32).abs().max() / f32.abs().max()), "min_cos": float(cos.min()),
-            "range": float(f32.abs().max())}
+    rng = float(f32.abs().max())
+    # max error / smallest cosine are EXTREME statistics of a few dozen frames (they move by +-40 % between two numerically
+    # equivalent kernels - round 5: the same attention with a different rescaling point); the RMS error and the mean 1 - cos are
+    # the stable ones, and what the tests bound tightly
+    return {"err_over_range": float((f16 - f32).abs().max() / rng), "min_cos": float(cos.min()), "range": rng,
+            "rms_err_over_range": float((f16 - f32).double().pow(2).mean().sqrt() / rng),
+            "mean_one_minus_cos": float((1.0 - cos.double()).mean())}
 
 
 def _normalize_u8(u8):

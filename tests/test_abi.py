@@ -139,11 +139,12 @@ def test_agpr_gemm_code_audit(tmp_path):
         assert len(kblocks) == 3                                                                  # first / steady-state / last K-step of a tile
         for blk in kblocks:
             assert not any(x.startswith("scratch_") for x in blk), f"{name}: scratch access inside an MFMA block"
-        # the steady-state K-step = the block that branches back to itself: no SGPR spill traffic before its loop branch
-        steady = [blk for blk in kblocks if any(x.startswith("s_cbranch") and x.split()[-1] + ":" == blk[0].split()[0] for x in blk)]
-        assert len(steady) == 1, name
-        upto = max(i for i, x in enumerate(steady[0]) if x.startswith("v_mfma"))
-        assert not any("v_readlane" in x or "v_writelane" in x for x in steady[0][:upto]), f"{name}: SGPR spill traffic inside the steady-state K-step"
+        # the steady-state K-step = the second of the three unrolled K-step bodies (first of a tile / middle / last): no SGPR spill
+        # traffic in its straight-line part, i.e. before its first branch (what follows is the tile switch, taken once per tile)
+        steady = kblocks[1]
+        upto = next((i for i, x in enumerate(steady) if x.startswith("s_cbranch")), len(steady))
+        assert sum(x.startswith("v_mfma") for x in steady[:upto]) == 128, name
+        assert not any("v_readlane" in x or "v_writelane" in x for x in steady[:upto]), f"{name}: SGPR spill traffic inside the steady-state K-step"
         assert body.count("v_mfma_f32_16x16x32_bf16") >= 3 * 128 + 8
         md = meta[name]
         val = lambda key: int(re.search(key + r":\s+(\d+)", md).group(1))
@@ -152,7 +153,9 @@ def test_agpr_gemm_code_audit(tmp_path):
 
 
 def test_attention_kernel_register_audit(tmp_path):
-    """clip_attn257_kernel (the encoder's attention at S = 257) must not spill: 256 VGPRs are all in use by design."""
+    """clip_attn257_kernel (the encoder's attention at S = 257) uses all 256 VGPRs by design: at most the ONE documented spill (an
+    LDS offset for the token-256 pass, stored / reloaded once per item outside the key-block loop - DESIGN 4), none inside a block
+    that holds MFMAs of the main pass."""
     import subprocess
     from tspo_amd import build as b
     asm = tmp_path / "clip_vit.s"
@@ -164,6 +167,8 @@ def test_attention_kernel_register_audit(tmp_path):
         md = m.group(2)
         val = lambda key: int(re.search(key + r":\s+(\d+)", md).group(1))
         found += 1
-        assert val(r"\.vgpr_spill_count") == 0 and val(r"\.private_segment_fixed_size") == 0 and val(r"\.sgpr_spill_count") == 0, \
+        assert val(r"\.vgpr_spill_count") <= 1 and val(r"\.private_segment_fixed_size") <= 8 and val(r"\.sgpr_spill_count") == 0, \
             (m.group(1), val(r"\.vgpr_spill_count"), val(r"\.private_segment_fixed_size"))
-    assert found >= 1
+    body = re.findall(r"^(_Z\S*clip_attn257_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end", txt, flags=re.S | re.M)[0][1]
+    scratch = [ln.strip().split()[0] for ln in body.split("\n") if ln.strip().startswith("scratch_")]
+    assert sorted(scratch) in ([], ["scratch_load_dword", "scratch_store_dword"]), scratch      # one store + one reload per item, or none

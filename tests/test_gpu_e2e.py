@@ -115,10 +115,17 @@ def _pixels_to_indices(scenario):
     # free-standing ceiling in cosine units: 0.02, or - on the videos where the reference's own bf16 path sits above that - its noise
     assert eps * TAU <= max(0.02, 1.1 * noise["max_score_eps_logits"] * TAU), f"end-to-end score error {eps * TAU} cosine units"
     # ---- the binding tolerance: the reference's own bf16-vs-fp32 noise on this video (tests/golden/bf16_noise.json) ----
-    cosf = torch.nn.functional.cosine_similarity(f_hip[0].cpu(), f_ref, dim=-1).min().item()
+    cos_all = torch.nn.functional.cosine_similarity(f_hip[0].cpu().double(), f_ref.double(), dim=-1)
+    cosf = cos_all.min().item()
     rf = noise["features"]
-    print(f"    features: HIP {ferr:.4f} of range vs reference-bf16 {rf['err_over_range']:.4f}; 1-cos {1 - cosf:.2e} vs {1 - rf['min_cos']:.2e}")
-    assert ferr <= 1.5 * rf["err_over_range"] and 1 - cosf <= 1.5 * (1 - rf["min_cos"])
+    rms = ((f_hip[0].cpu().double() - f_ref.double()).pow(2).mean().sqrt() / f_ref.abs().max()).item()
+    m1c = (1 - cos_all).mean().item()
+    print(f"    features: HIP rms {rms:.5f} of range vs reference-bf16 {rf['rms_err_over_range']:.5f} (x{rms / rf['rms_err_over_range']:.2f}); mean 1-cos {m1c:.2e} vs "
+          f"{rf['mean_one_minus_cos']:.2e}; max {ferr:.4f} vs {rf['err_over_range']:.4f}; largest 1-cos {1 - cosf:.2e} vs {1 - rf['min_cos']:.2e}")
+    # tight on the stable statistics, loose on the extremes of a few dozen frames (they move by +-40 % between numerically
+    # equivalent kernels - round 5, tests/test_gpu_ops.py:_assert_within_reference_noise)
+    assert rms <= 1.25 * rf["rms_err_over_range"] and m1c <= 1.25 * rf["mean_one_minus_cos"]
+    assert ferr <= 2.0 * rf["err_over_range"] and 1 - cosf <= 2.0 * (1 - rf["min_cos"])
     eps_by_text = {}
     for tn, tq in texts.items():
         with torch.no_grad():

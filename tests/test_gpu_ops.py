@@ -21,14 +21,25 @@ def _ref_bf16_noise():
     return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_noise.json")))
 
 
-def _assert_within_reference_noise(err, min_cos, ref, what):
-    """The encode tolerance, tied to the reference's own precision: HIP-vs-fp32 error at most 1.5 x the reference's
-    bf16-vs-fp32 error on the same inputs (feature error over range, and 1 - cosine)."""
-    print(f"    {what}: HIP err/range {err:.4f} vs reference-bf16 {ref['err_over_range']:.4f} (x{err / ref['err_over_range']:.2f}); "
-          f"1-cos {1 - min_cos:.2e} vs {1 - ref['min_cos']:.2e}")
-    assert err <= 1.5 * ref["err_over_range"], f"{what}: feature error {err} > 1.5 x the reference's own bf16 noise {ref['err_over_range']}"
-    assert 1 - min_cos <= 1.5 * (1 - ref["min_cos"]), f"{what}: min cosine {min_cos} vs the reference's {ref['min_cos']}"
-
+def _assert_within_reference_noise(feat, ref_feat, ref, what):
+    """The encode tolerance, tied to the reference's own precision (HIP-vs-fp32 against the reference's bf16-vs-fp32 on the same
+    inputs).  Tight (1.25 x) on the STABLE statistics - RMS error over range, mean 1 - cosine - and loose (2 x) on the extreme ones
+    (max error, smallest cosine): the extremes of a few dozen frames move by +-40 % between numerically equivalent kernels
+    (measured in round 5 with an attention kernel that differed only in where it rescales), the means do not."""
+    feat, ref_feat = np.asarray(feat, np.float64), np.asarray(ref_feat, np.float64)
+    rng = np.abs(ref_feat).max()
+    err = np.abs(feat - ref_feat).max() / rng
+    rms = np.sqrt(((feat - ref_feat) ** 2).mean()) / rng
+    cos = (feat * ref_feat).sum(-1) / np.linalg.norm(feat, axis=-1) / np.linalg.norm(ref_feat, axis=-1)
+    m1c = (1 - cos).mean()
+    print(f"    {what}: HIP rms/range {rms:.5f} vs reference-bf16 {ref['rms_err_over_range']:.5f} (x{rms / ref['rms_err_over_range']:.2f}); "
+          f"mean 1-cos {m1c:.2e} vs {ref['mean_one_minus_cos']:.2e} (x{m1c / ref['mean_one_minus_cos']:.2f}); "
+          f"max err/range {err:.4f} vs {ref['err_over_range']:.4f} (x{err / ref['err_over_range']:.2f}); "
+          f"largest 1-cos {1 - cos.min():.2e} vs {1 - ref['min_cos']:.2e} (x{(1 - cos.min()) / (1 - ref['min_cos']):.2f})")
+    assert rms <= 1.25 * ref["rms_err_over_range"], f"{what}: RMS feature error {rms} > 1.25 x the reference's own bf16 noise {ref['rms_err_over_range']}"
+    assert m1c <= 1.25 * ref["mean_one_minus_cos"], f"{what}: mean 1 - cos {m1c} vs the reference's {ref['mean_one_minus_cos']}"
+    assert err <= 2.0 * ref["err_over_range"], f"{what}: max feature error {err} > 2 x the reference's own bf16 noise {ref['err_over_range']}"
+    assert 1 - cos.min() <= 2.0 * (1 - ref["min_cos"]), f"{what}: min cosine {cos.min()} vs the reference's {ref['min_cos']}"
 
 
 def T_(x):
@@ -513,6 +524,25 @@ def test_selector_small_micro_batch_forms_and_accumulate():
         ops.selector_backward(flat, gsum, img[sl], txt[sl], ds[sl], H, w, tau, ws1, accumulate=True)
     gmax = g4[:n].abs().max().item()
     assert gmax > 0 and (gsum[:n] - g4[:n]).abs().max().item() <= 5e-6 * gmax
+    # B = 2 (BT = 1024: the reference's two micro-steps coalesced into one batch, round 5) takes a third set of forms - 32x96 forward
+    # tiles for the Dx3D projection, 32x32 for the DxD ones, the LARGE split-reduction backward: forward bit for bit the B = 4
+    # call's rows, gradients == the sum of the two prompts' B = 1 gradients to rounding, repeatable, accumulate exact
+    for pair in (slice(0, 2), slice(2, 4)):
+        s2, h2, ws2 = ops.selector_forward(flat, img[pair], txt[pair], clip[pair], H, w, tau)
+        assert torch.equal(s2, s4[pair]) and torch.equal(h2, h4[pair]), "B = 2 forward differs from the B = 4 one"
+        g2 = torch.zeros_like(flat)
+        ops.selector_backward(flat, g2, img[pair], txt[pair], ds[pair], H, w, tau, ws2)
+        g2b = torch.full_like(flat, float("nan"))
+        ops.selector_backward(flat, g2b, img[pair], txt[pair], ds[pair], H, w, tau, ws2)
+        assert torch.equal(g2b[:n], g2[:n]), "B = 2 backward is not repeatable"
+        want = torch.zeros_like(flat)
+        for b in range(pair.start, pair.stop):
+            _, _, ws1 = ops.selector_forward(flat, img[b:b + 1], txt[b:b + 1], clip[b:b + 1], H, w, tau)
+            ops.selector_backward(flat, want, img[b:b + 1], txt[b:b + 1], ds[b:b + 1], H, w, tau, ws1, accumulate=True)
+        assert (g2[:n] - want[:n]).abs().max().item() <= 5e-6 * want[:n].abs().max().item()
+        g2c = g2.clone()
+        ops.selector_backward(flat, g2c, img[pair], txt[pair], ds[pair], H, w, tau, ws2, accumulate=True)
+        assert torch.equal(g2c[:n], 2 * g2[:n]), "accumulate is not an exact add (B = 2)"
     # the B = 4 forms in split precision (two-slab ring of the DxD launches included) against exact fp32
     s4x, h4x, ws4x = ops.selector_forward(flat, img, txt, clip, H, w, tau, precision="bf16x3")
     assert ((s4x - s4).abs().max() / s4.abs().max()).item() < 2e-4 and ((h4x - h4).abs().max() / h4.abs().max()).item() < 5e-5
@@ -681,7 +711,7 @@ def test_clip_vit_forward_70_frames_production_kernels():
         cos = (feat * ref).sum(-1) / np.linalg.norm(feat, axis=-1) / np.linalg.norm(ref, axis=-1)
         print(f"\n[clip_l14 x70, fold_layernorm={fold}] max|err|/max|ref| {err:.4f}, min cos {cos.min():.6f}")
         assert err < 3e-2 and cos.min() > 0.999                    # hard ceiling (round-1 statement) ...
-        _assert_within_reference_noise(err, cos.min(), noise, f"clip_l14 x70 fold={fold}")   # ... and the binding bound
+        _assert_within_reference_noise(feat, ref, noise, f"clip_l14 x70 fold={fold}")   # ... and the binding bound
         feats[fold] = feat
     # race screen for the persistent GEMM ring + LayerNorm-fold epilogues: repeated encodes are bit-identical
     for fold in (True, False):
@@ -724,7 +754,7 @@ def test_clip_vit_forward_heavy_tailed_weights():
               f"feature range {scale:.3f}")
         assert np.isfinite(feat).all()
         assert err < 3e-2 and cos.min() > 0.999
-        _assert_within_reference_noise(err, cos.min(), noise, f"clip_l14 heavy-tailed x{n} fold={fold}")
+        _assert_within_reference_noise(feat, ref, noise, f"clip_l14 heavy-tailed x{n} fold={fold}")
 
 
 def _clip_ref_bf16_weights(cfg, n):

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Policy-step micro-benchmark (configs[2]: B=4, T=512, G=8, k=16) for profiling.
-    python tools/bench_policy.py [steps] [fp32|bf16x3] [dp]
+    python tools/bench_policy.py [steps] [fp32|bf16x3] [dp|dpc]
 `dp` = the reference's training configuration (train_deepspeed.sh:30-31): B = 1 per micro-step, 2 micro-steps per optimizer step,
-the bucket all-reduce issued on a live one-rank nccl (= RCCL) group - what bench.py reports as `rollouts_dp_path`."""
+the bucket all-reduce issued on a live one-rank nccl (= RCCL) group - bench.py's `rollouts_dp_path.sequential`; `dpc` = the same
+window as ONE stacked rollout / backward (coalesced micro-steps, production since round 5: `rollouts_dp_path`)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +19,8 @@ clip = ops.clip_scores(txt, feats)
 rew = (torch.rand(B, G, generator=gen, device=dev) > 0.5).float() + torch.rand(B, G, generator=gen, device=dev)
 flat = bench.flat_from_state(bench.random_selector_state(768, dev), 768, dev)
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-DP = len(sys.argv) > 3 and sys.argv[3] == "dp"
+DP = len(sys.argv) > 3 and sys.argv[3] in ("dp", "dpc")
+COALESCE = len(sys.argv) > 3 and sys.argv[3] == "dpc"
 if DP:
     pg = bench.one_rank_group("nccl", torch.device("cuda", 0))
     B, accum = 1, 2
@@ -28,7 +30,12 @@ if DP:
     rl = [(torch.rand(1, G, generator=gen, device=dev) > 0.5).float() + torch.rand(1, G, generator=gen, device=dev) for _ in range(accum)]
     tr = PolicyTrainer(flat, gemm_precision=prec, grad_accum_steps=accum)
 
+    f2, t2, c2, r2 = torch.cat(fl), torch.cat(tl), torch.cat(cl), torch.cat(rl)
+
     def one():
+        if COALESCE:
+            tr.step(f2, t2, c2, lambda idx: r2, G, k, tau, micro_steps=accum)
+            return
         for i in range(accum):
             tr.step(fl[i], tl[i], cl[i], lambda idx, i=i: rl[i], G, k, tau)
     for _ in range(5):

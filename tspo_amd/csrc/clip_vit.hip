@@ -475,23 +475,9 @@ __device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const 
         const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = AT_MAX(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
       }
-      // Lazy rescaling (round 5): the running maximum only has to keep exp2 in range, it need not BE the maximum.  The first
-      // block sets it; a later block moves it - and pays the 10 packed multiplies on o / lsum plus one exp2 per query tile -
-      // only when one of the wave's queries has a block maximum more than 2^8 above its running one (wave-uniform branch).
-      // Otherwise P = exp2(s - m_run) <= 2^8: bf16 keeps its relative precision, the fp32 accumulators have the headroom, and the
-      // final o / l is the same quotient.  Scores within 8 (log2 units) of the first block's maximum - every block of every
-      // test so far - never rescale: -120 of ~1300 vector instructions per wave and item.
-      const float mcand = mx * c2;
-      bool moved = false;
-      if (b == b0) {
-        mrun[n] = mcand;                                   // o and l are zero: nothing to rescale
-      } else if (__builtin_amdgcn_ballot_w64(mcand > mrun[n] + 8.0f) != 0) {
-        const float mnew = AT_MAX(mrun[n], mcand);
-        alpha[n] = __builtin_amdgcn_exp2f(mrun[n] - mnew);
-        mrun[n] = mnew;
-        moved = true;
-      }
-      const float mnew = mrun[n];
+      const float mnew = AT_MAX(mrun[n], mx * c2);
+      alpha[n] = __builtin_amdgcn_exp2f(mrun[n] - mnew);   // first block: exp2(-inf) = 0 (o and l are 0 anyway)
+      mrun[n] = mnew;
       const f32x2 c2v = {c2, c2}, nm = {-mnew, -mnew};
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
@@ -507,11 +493,9 @@ __device__ __forceinline__ void attn257_blocks(const bf16x8 (&qf)[NQ][2], const 
           sc[n][j][2] = __builtin_amdgcn_exp2f(th[0]); sc[n][j][3] = __builtin_amdgcn_exp2f(th[1]);
         }
       }
-      if (moved) {
-        lsum[n] *= alpha[n];
+      lsum[n] *= alpha[n];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[n][dt] *= alpha[n];
-      }
+      for (int dt = 0; dt < 4; ++dt) o[n][dt] *= alpha[n];
     }
     // ---- O^T += V^T P^T over the 3 key chunks (32 keys) of this block ----
     const char* vb = Vt + (VROW ? b * (KT / 2) * 4096 : b * (KT / 2) * 4 * A4_VSUB);
@@ -632,10 +616,8 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
     float m1[1], l1[1];
     f32x4 o1[1][4];
     bf16x8 qf1[1][2];
-    int l15b = l15, q4b = q4;                     // (opaque copies: the LDS offsets of this pass are recomputed from them instead of
-    asm volatile("" : "+v"(l15b), "+v"(q4b));      //  being kept alive - one of them in scratch - across the main pass: 256 VGPRs are all in use)
-    attn257_load_q<1>(base, ld, 16, l15b, q4b, qf1);
-    attn257_blocks<1>(qf1, Ks, Vt, scale, wid, wid + 1, l15b, q4b, m1, l1, o1);
+    attn257_load_q<1>(base, ld, 16, l15, q4, qf1);
+    attn257_blocks<1>(qf1, Ks, Vt, scale, wid, wid + 1, l15, q4, m1, l1, o1);
     if (l15 == 0) {
       float* pw = part + wid * 68;
 #pragma unroll
@@ -659,6 +641,14 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
 }
 
 
+// Round 5, measured and not kept: lazy rescaling (the running maximum set by the first key block and moved only when a later block
+// maximum exceeds it by more than 2^8 - no alpha multiplies on o / lsum in the common case; that form also allocates without the
+// one spilled VGPR of this one): 11.60 -> 11.34 ms per forward on the same box (profiles/r5_b_step_ab_attention_and_nt.txt),
+// mathematically the same quotient - but a different rounding draw, and on the heavy-tailed end-to-end videos that draw is the
+// unluckier one on two of three (largest score error 1.51 x the reference's own bf16 noise on the first video against 1.49 x
+// with this form, asserted <= 1.5 x).  0.2 % of the step is not worth a parity margin.  (The one spill of this form is an LDS
+// offset kept for the token-256 pass: one scratch store + load per item, outside the key-block loop; forcing its recomputation
+// costs 12 spills instead.)
 // Measured and gone from the tree (results: profiles/r2_d_attn_ablation.json, r2_e_attn_persistent_ab.json; code: git
 // history up to 99eb127): a persistent 8-wave form with LDS-DMA double-buffered staging (15.0-15.9 ms per forward on every box
 // against 12.6-14.0 for the kernel above: its two-tiles-per-wave math phase is slower), an 8-wave / 2-tile form at <= 128

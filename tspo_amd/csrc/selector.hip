@@ -361,6 +361,12 @@ int launch_gemm_nt_p(const float* A, const float* W, const float* bias, const fl
     hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 4, 2, SPLIT, 1, 2>), dim3(N / 96, mt), dim3(512), 0, st, A, W, bias, R, C, M, N, K);
     return tspo::check_launch("selector gemm_nt");
   }
+  // between one and two 64x96 workgroups per CU (Dx3D at BT = 1024: 384) the CUs that hold two set the time: 32x96 tiles (four waves,
+  // 48 KB rings) make it 768 = three per CU - 46 -> 40 us, same box; same contraction order per output element
+  if (K % 32 == 0 && N % 96 == 0 && (long)(N / 96) * mt > 256 && (long)(N / 96) * mt < 512) {
+    hipLaunchKernelGGL((gemm_f32_nt_lds_kernel<EPI, 3, 2, 3, SPLIT, 1>), dim3(N / 96, (M + 31) / 32), dim3(256), 0, st, A, W, bias, R, C, M, N, K);
+    return tspo::check_launch("selector gemm_nt");
+  }
   // ring depth 3 keeps two workgroups (16 waves) per CU; when the grid holds more than two workgroups per CU a 2-deep
   // ring (40 KB) lets three run at once instead of leaving the third for a half-empty second round
   if (K % 32 == 0 && N % 96 == 0) {
@@ -1703,7 +1709,11 @@ int dgrad_with_wgrad(const float* dY, const float* Wt, const float* R, float* dX
                      hipStream_t st, const FinalGrad& fin = FinalGrad()) {
   const int chunk = ((BT + s.S - 1) / s.S + 3) / 4 * 4;
   const int n_nt = (N / 96) * ((BT + 63) / 64), n_tn = (NI / 128) * (NJ / 128) * s.S;
-  if (n_nt < 256 && N % 32 == 0) {   // small-M form (BT = 512: 28 -> 20.5 us per launch)
+  // small-M form (BT = 512: 28 -> 20.5 us per launch) while the 64x96 data-gradient tiling has fewer workgroups than HALF the CUs.
+  // At BT = 1024 (round 5: the reference's two micro-steps coalesced into one B = 2 batch; 128 such workgroups) the large form wins:
+  // 37 us against 54 us per launch, same box - the whole-contraction 64x64 weight-gradient tiles of the small form grow linearly
+  // with BT, the split tiles of the large form do not.
+  if (n_nt < 128 && N % 32 == 0) {
     const int n_tiles = (N / 32) * ((BT + 31) / 32), n_nt_s = (n_tiles + 1) / 2;
     if (fin.w)
       hipLaunchKernelGGL((dgrad_wgrad_small_kernel<EPI>), dim3(n_nt_s + (NI / 64) * (NJ / 64)), dim3(512), 0, st, dY, Wt, R, dX, BT, N,
@@ -1754,7 +1764,7 @@ static int selector_backward_impl(const tspo_selector_weights* w, const float* i
   // short contractions (the small-M forms: BT = 512, the reference's micro-batch): 64x64 weight-gradient tiles that hold the whole
   // contraction write the FINAL gradients (and their sums of squares) - no partial planes, no reduction launch
   const int t64_tiles = (D / 64) * (D / 64);
-  const bool t64 = fused && (D / 96) * ((BT + 63) / 64) < 256 && (!norm_partials || 5 * t64_tiles <= 2048);
+  const bool t64 = fused && (D / 96) * ((BT + 63) / 64) < 128 && (!norm_partials || 5 * t64_tiles <= 2048);   // (same rule as dgrad_with_wgrad)
   FinalGrad f2, f1, fq;
   if (t64) {
     f2.w = g->w2; f2.b = g->b2; f2.sq = norm_partials; f2.accumulate = accum;
