@@ -552,10 +552,11 @@ def main():
         if evs:
             per_step.extend(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
         if per_rank is not None:
-            if world > 1:
-                allt = [torch.zeros_like(dt_) for _ in range(world)]
-                dist.all_gather(allt, dt_)
-                per_rank.extend(float(x.item()) for x in allt)
+            if world > 1:      # (an all-reduce of a one-hot-placed vector: works on every backend, also gloo with device tensors)
+                allt = torch.zeros(world, device=dev, dtype=torch.float64)
+                allt[rank] = dt_[0]
+                dist.all_reduce(allt, op=dist.ReduceOp.SUM)
+                per_rank.extend(float(x) for x in allt.tolist())
             else:
                 per_rank.append(float(dt_.item()))
         if world > 1:

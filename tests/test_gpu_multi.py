@@ -57,6 +57,8 @@ def test_bench_self_spawns_two_ranks_from_a_bare_shell():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["launcher"] == "self-spawn" and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["rollouts_per_s"] > 0 and line["steps"] == 2
+    by_rank = line["ms_per_step_by_rank"]             # every rank's own clock over the timed region: a slow rank must be visible
+    assert len(by_rank) == 2 and all(t > 0 for t in by_rank) and abs(max(by_rank) - line["ms_per_step"]) < 1e-3 * line["ms_per_step"] + 1e-3
     comm = line["comm"]
     assert comm["backend"] == "gloo" and comm["world"] == 2 and comm["allreduce_us"] > 0 and comm["sum_correct"] is True
     assert "error" not in comm
