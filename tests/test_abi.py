@@ -94,7 +94,7 @@ def test_shipped_library_has_no_dev_hooks():
 # SGPR spills (v_writelane / v_readlane into a spare VGPR, no memory traffic) hipcc leaves in each epilogue form of the production GEMM:
 # none in the steady-state K-step of any form; the counts below are prologue / tile-switch / epilogue / remainder-phase code.  An
 # upper bound per form, so that DESIGN.md cannot drift from the binary again.
-A9_SGPR_SPILL_BOUND = {0: 0, 1: 0, 2: 8, 3: 0, 4: 12, 5: 4, 6: 4, 7: 64, 8: 0}
+A9_SGPR_SPILL_BOUND = {0: 0, 1: 0, 2: 24, 3: 0, 4: 12, 5: 4, 6: 4, 7: 72, 8: 0}
 
 
 def test_agpr_gemm_code_audit(tmp_path):
@@ -135,7 +135,8 @@ def test_agpr_gemm_code_audit(tmp_path):
         assert not bad, f"{name}: compiler-emitted AGPR access outside the asm statements: {bad[:3]}"
         assert not m0bad, f"{name}: compiler-emitted m0 use next to the hand-written LDS-DMA: {m0bad[:3]}"
         assert not any(x.startswith("scratch_") for blk in blocks for x in blk), f"{name}: scratch access"
-        kblocks = [blk for blk in blocks if sum(x.startswith("v_mfma") for x in blk) >= 32]       # the K-step bodies
+        kblocks = [blk for blk in blocks if sum(x.startswith("v_mfma") for x in blk) >= 100]      # the K-step bodies (the epilogue of the
+        # residual forms holds MFMAs too since round 5 - residual rows and row statistics on the matrix pipe - in blocks of at most 72)
         assert len(kblocks) == 3                                                                  # first / steady-state / last K-step of a tile
         for blk in kblocks:
             assert not any(x.startswith("scratch_") for x in blk), f"{name}: scratch access inside an MFMA block"

@@ -79,6 +79,14 @@ struct A9ScheduleProduction {
   }
 };
 
+// Where the last K-step of a tile issues residual load i (0-15) of the residual forms: behind B3 (gap 85), in gaps without a DMA.
+constexpr int a9_resid_slot(int gap) {
+  constexpr int at[16] = {86, 87, 89, 93, 95, 99, 101, 105, 107, 111, 113, 117, 119, 123, 125, 127};
+  for (int i = 0; i < 16; ++i)
+    if (at[i] == gap) return i;
+  return -1;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Remainder phase (round 5).  Whole 256x256 tiles are handed out in whole ROUNDS only: XCD set x owns ntile_x tiles, its 32
 // workgroups run floor(ntile_x / 32) of them each.  What is left over (out-proj / fc2 of the encoder: 4 112 tiles = 16.06 rounds,
@@ -159,8 +167,21 @@ __device__ __forceinline__ void a9_tail_subtile(const GemmArgs& g, char* lds, in
       for (int ni = 0; ni < 4; ++ni)   // inline asm with VGPR accumulators: hipcc must not pick AGPRs in this kernel (it would for the builtin)
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[ni]) : "v"(fw[kh][ni]), "v"(fa[kh]));
   }
-  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // last MFMA's result -> first VALU read (the hazard recogniser does not see asm MFMAs)
   const int m = m_s + wid * 16 + l15;
+  if (EPI == GE_RESID || EPI == GE_RESID_ST) {   // the residual rows onto the accumulators, exactly as the whole-tile epilogue does it
+    const i32x4 sel0 = epi_resid_sel(0, l15, q4), sel1 = epi_resid_sel(1, l15, q4);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int n = n_s + (2 * pr + (q4 & 1)) * 16 + (q4 >> 1) * 8;
+      const uint4 rv = (m < g.M && n < g.N) ? *reinterpret_cast<const uint4*>(g.R + (size_t)m * g.N + n) : make_uint4(0u, 0u, 0u, 0u);
+      const i32x4 rf = {(int)rv.x, (int)rv.y, (int)rv.z, (int)rv.w};
+      epi_resid_mfma(acc[2 * pr], sel0, rf);
+      epi_resid_mfma(acc[2 * pr + 1], sel1, rf);
+    }
+  }
+  // last MFMA's result -> first VALU read (the hazard recogniser does not see asm MFMAs); the accumulators are operands of the
+  // wait so that no read of them can be scheduled in front of it
+  asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
   EpiCols ec;
   g3_epi_cols<EPI>(g, n_s, 0, q4, ec);
   const float2 rst = epi_is_ln(EPI) ? g3_epi_rowstat(g, m) : make_float2(1.f, 0.f);
@@ -186,6 +207,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
   const int my_tiles = wl < lim ? (lim - wl + nwl - 1) / nwl : 0;
   if (my_tiles == 0 && !tail) return;
   A4_FENCE();   // claims a[0:255] for this kernel
+  // (Measured in round 5 and not kept - profiles/r5_e_gemm_epilogue_experiments.txt: workgroup b started b * w / 256 cycles late, w = 8k
+  // ... 65k cycles, so that the 256 epilogues of a round of tiles - 33-67 MB of stores and residual loads - do not reach the memory
+  // system in the same few microseconds: no shape gets faster at any window, every shape pays the window.  The epilogue is a
+  // per-CU limit, not a chip-level burst.)
 
   if (my_tiles > 0) {
   // ---- LDS-DMA: piece P = wid*8 + q of a region = rows 8P..8P+7 (1 KB); lane (rin, slot) brings global chunk slot ^ rin.
@@ -255,6 +280,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
   for (int i = 0; i < 8; ++i) { fa0[i] = ldfrag(lds + fbaseA + i * 2048 + co0); fw0[i] = ldfrag(lds + fbaseW + i * 2048 + co0); }
 
   int it = 0, c_s = wl;
+  constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
+  EpiRes rres;   // (the residual forms: slice 0's rows, requested from the last K-step of the tile)
   auto kstep = [&](auto zero_, auto last_) {
     constexpr bool ZERO = decltype(zero_)::value, LAST = decltype(last_)::value;
     const int cb = it & 1;
@@ -275,6 +302,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
         if constexpr (op >= OP_RW1 && op < OP_RW1 + 8) fw1[op - OP_RW1] = ldfrag(cur + fbaseW + (op - OP_RW1) * 2048 + co1);
         if constexpr (!LAST && op >= OP_RA0 && op < OP_RA0 + 8) fa0[op - OP_RA0] = ldfrag(nxt + fbaseA + (op - OP_RA0) * 2048 + co0);
         if constexpr (!LAST && op >= OP_RW0 && op < OP_RW0 + 8) fw0[op - OP_RW0] = ldfrag(nxt + fbaseW + (op - OP_RW0) * 2048 + co0);
+        // last K-step of a tile: no next-stage fragments (the epilogue comes first) - the residual forms request the 16 residual
+        // loads of slice 0 there instead (row block by row block, the order the epilogue consumes them), into the registers K-half
+        // 0's fragments have left: one load per gap that holds no DMA, from the barrier to the end of the K-step
+        if constexpr (LAST && RES) {
+          constexpr int ri = a9_resid_slot(gap);
+          if constexpr (ri >= 0) epi_rload(g, 0, ri >> 1, ri & 1, rres);
+        }
         if constexpr (op >= OP_MA && op < OP_MA + 8) set_m0(std::integral_constant<int, op - OP_MA>{}, std::false_type{}, bb);
         if constexpr (op >= OP_DA && op < OP_DA + 8) dma(std::integral_constant<int, op - OP_DA>{}, std::false_type{}, vo);
         if constexpr (op >= OP_MW && op < OP_MW + 8) set_m0(std::integral_constant<int, op - OP_MW>{}, std::true_type{}, bb);
@@ -305,10 +339,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_a9_kernel(GemmArgs g, int ti
     kstep(std::true_type{}, std::false_type{});
     for (int kt = 1; kt < nk - 1; ++kt) kstep(std::false_type{}, std::false_type{});
     EpiPre p0;                                                 // slice 0's epilogue inputs arrive behind the last K-step
+    EpiRows prow;                                              // and so do the row statistics of the LayerNorm-folded forms
     epi_prefetch<EPI>(g, n0, wn * 2, q4, p0);
+    epi_prefetch_rows<EPI>(g, m0, wm, l15, prow);
+    if (RES) epi_res_setup(g, m0, n0, wm, wn, l15, q4, rres);
     kstep(std::false_type{}, std::true_type{});
-    if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0);
-    else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0);
+    if (m0 + G3_BM <= g.M && n0 + G3_BN <= g.N) agpr_epilogue<EPI, true>(g, m0, n0, wm, wn, l15, q4, p0, prow, rres);
+    else agpr_epilogue<EPI, false>(g, m0, n0, wm, wn, l15, q4, p0, prow, rres);
     c_s += nwl;
     const char* nbuf = lds + (it & 1) * G3_STAGE;              // the next tile's first fragments, behind the epilogue
 #pragma unroll

@@ -44,14 +44,32 @@ __device__ __forceinline__ float2 g3_epi_rowstat(const GemmArgs& g, int m) {   /
 }
 
 // v[ni] = the 4 accumulators of column tile ni for row m (lane l15 of the 16-row block), rst = g3_epi_rowstat(m)
-// PRE: bias / folded bias comes from ec.bias and the residual from rpre[ni] (this lane's 4 bf16 of column tile ni, MFMA
-// layout) - both fetched by the caller ahead of time - instead of being loaded here.
+// PRE: bias / folded bias comes from ec.bias (fetched by the caller ahead of time) instead of being loaded here.
 // FULL: the caller guarantees that the whole 256x256 tile lies inside the matrix (no per-element range predicates).
+// Residual forms (round 5): the caller has ALREADY added the residual rows to the accumulators - on the matrix pipe
+// (epi_resid_mfma below), which idles in the epilogue while the vector pipe was its limit: the unpack / add / un-swap of the
+// residual and the two-pass row statistics were 1 400 of the 2 330 vector instructions of a tile's residual + statistics epilogue.
+typedef __attribute__((ext_vector_type(4))) int epi_i32x4;
+// a[i][k] = 1 where k-slot k of the residual fragment holds column 16 t + i of its 32-column pair, else 0 (bf16).  The residual
+// fragment is the 16-byte load of the store mapping: lane (row l15, q4) holds columns (q4 & 1) * 16 + (q4 >> 1) * 8 + e, e = 0..7.
+__device__ __forceinline__ epi_i32x4 epi_resid_sel(int t, int l15, int q4) {
+  const bool on = (q4 & 1) == t && (q4 >> 1) == (l15 >> 3);
+  const int e = l15 & 7;
+  epi_i32x4 s;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) s[d] = !on ? 0 : (e == 2 * d ? 0x00003f80 : (e == 2 * d + 1 ? 0x3f800000 : 0));
+  return s;
+}
+// acc += the residual values of one 16-row x 16-column tile: D[i][j] = C[i][j] + sum_k sel[i][k] R[j][k] (one exact product per output)
+__device__ __forceinline__ void epi_resid_mfma(f32x4& acc, const epi_i32x4 sel, const epi_i32x4 rfrag) {
+  // (s_nop: hipcc may assemble an operand tuple with v_movs right in front of an asm statement, and nothing interlocks a VALU
+  // write with the MFMA's operand read - it does not see the MFMA inside the asm; measured: garbage without it)
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(sel), "v"(rfrag));
+}
 template <int EPI, bool PRE = false, bool FULL = false>
 __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], const EpiCols& ec, float2 rst, int m, int n0,
-                                           int wn, int q4, const float* lbias, const uint2* rpre = nullptr) {
+                                           int wn, int q4, const float* lbias) {
   constexpr bool LN = epi_is_ln(EPI);
-  constexpr bool RES = EPI == GE_RESID || EPI == GE_RESID_ST;
   size_t orow = (size_t)m;
   int prow = 0;
   if (EPI == GE_PATCH) {
@@ -60,8 +78,6 @@ __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], co
     orow = (size_t)f * (g.P + 1) + prow;
   }
   const float rs = rst.x, mu = rst.y;   // rstd, -mean * rstd
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  f32x2_t st_lo[4], st_hi[4];   // GE_RESID_ST: the 16 values of this lane as stored (bf16-rounded), kept for the second pass
   uint2 pk[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
@@ -88,53 +104,43 @@ __device__ __forceinline__ void g3_epi_row(const GemmArgs& g, f32x4 (&vv)[4], co
     }
     const size_t o = orow * g.N + n;
     if (EPI == GE_PATCH && ok) v += *reinterpret_cast<const f32x4*>(g.pos + (size_t)prow * g.N + n);
-    if (RES && (PRE || ok)) {
-      const uint2 rv = PRE ? rpre[ni] : *reinterpret_cast<const uint2*>(g.R + o);
-      v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
-      v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
-    }
     if (EPI == GE_F32) {
       if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + o) = v;
     } else {
       pk[ni].x = pack_bf16x2(v[0], v[1]);
       pk[ni].y = pack_bf16x2(v[2], v[3]);
-      if (EPI == GE_RESID_ST) {   // statistics of the values as stored (bf16-rounded): what the next GEMM reads
-        const float keep = ok ? 1.f : 0.f;   // (FULL: constant 1)
-        st_lo[ni] = f32x2_t{__uint_as_float(pk[ni].x << 16), __uint_as_float(pk[ni].x & 0xffff0000u)} * keep;
-        st_hi[ni] = f32x2_t{__uint_as_float(pk[ni].y << 16), __uint_as_float(pk[ni].y & 0xffff0000u)} * keep;
-      }
     }
   }
-  if (EPI == GE_RESID_ST) {   // the row's 64 columns of this slice live in the 4 lanes that share l15
-    // per-slice (mean, centred sum of squares): two passes over the 16 stored values of this lane (packed adds / fmas),
-    // so the later combination of the N/64 slices (Chan et al.) is as robust as a two-pass LayerNorm.  The 4-lane sums
-    // use v_permlane16/32_swap: no LDS round trip (ds_bpermute) in the middle of the epilogue.
-    // Contraction is OFF in this block and every fused multiply-add is spelled out: this code is instantiated several times
-    // per kernel (two slices of the whole-tile epilogue, the 64x64 remainder sub-tiles) and hipcc's choice of what to fuse differed
-    // between the copies - 1 ulp in the sum of squares of odd slices (round 5, found by the frame-permutation test) - which
-    // made a frame's features depend on WHERE in the batch it sat.  Now every copy performs the same operations.
+  if (EPI == GE_RESID_ST) {
+    // per-slice (mean, centred sum of squares) of the row's 64 values AS STORED (bf16-rounded: what the next GEMM reads), on the
+    // matrix pipe: the lane's 16 packed values are two 16x16x32 operands (8 values each; which k-slot holds which column does not
+    // matter for a sum); ones x V gives every lane its row's sum over the 4 lanes that share l15 (no cross-lane step), V x V the
+    // row's sum of squares on the diagonal (lane q4 == l15 >> 2, register l15 & 3) - products of bf16 values are exact in fp32 and
+    // the accumulation is fp32.  M2 = sum x^2 - sum x * mean: the cancellation is bounded by eps * sum x^2 / M2 per slice, and a
+    // slice whose 64 columns are that constant contributes nothing to the row's variance (the slices are merged with Chan's
+    // formula by stats_finalize, whose between-slice term is exact).  Every copy of this block (two slices of the whole-tile
+    // epilogue, the 64x64 remainder sub-tiles) feeds the same operands in the same k-slots: bitwise the same statistics.
+    const epi_i32x4 v01 = {(int)pk[0].x, (int)pk[0].y, (int)pk[1].x, (int)pk[1].y};
+    const epi_i32x4 v23 = {(int)pk[2].x, (int)pk[2].y, (int)pk[3].x, (int)pk[3].y};
+    const epi_i32x4 ones = {0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
+    f32x4 sm, sq;
+    // (s_nop in front of each: the packs / the compiler's operand-tuple moves have just written the inputs, see epi_resid_mfma)
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(sm) : "v"(ones), "v"(v01));
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(sq) : "v"(v01), "v"(v01));
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(sm) : "v"(ones), "v"(v23));
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(sq) : "v"(v23), "v"(v23));
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sm), "+v"(sq));   // MFMA result -> VALU read (the hazard recogniser does not see asm MFMAs)
+    {
 #pragma clang fp contract(off)
-    auto sum4 = [](float x) {
-      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-      x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-      const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-      return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-    };
-    f32x2_t s2 = (st_lo[0] + st_hi[0]) + (st_lo[1] + st_hi[1]);
-    s2 = s2 + ((st_lo[2] + st_hi[2]) + (st_lo[3] + st_hi[3]));
-    const float smean = sum4(s2[0] + s2[1]) * (1.0f / 64.0f);
-    const f32x2_t mm = {smean, smean};
-    f32x2_t q2 = {0.f, 0.f};
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const f32x2_t d0 = st_lo[ni] - mm, d1 = st_hi[ni] - mm;
-      q2 = __builtin_elementwise_fma(d0, d0, q2);
-      q2 = __builtin_elementwise_fma(d1, d1, q2);
+      const int l15 = threadIdx.x & 15;
+      const float rsum = sm[0];
+      const float smean = rsum * (1.0f / 64.0f);
+      const float x2 = (l15 & 2) ? ((l15 & 1) ? sq[3] : sq[2]) : ((l15 & 1) ? sq[1] : sq[0]);
+      const float ssq = fmaxf(__builtin_fmaf(-rsum, smean, x2), 0.f);
+      const int cslice = (n0 >> 6) + wn;
+      if (q4 == (l15 >> 2) && (FULL || (m < g.M && cslice * 64 < g.N)))
+        *reinterpret_cast<float2*>(g.spart + ((size_t)m * (g.N >> 6) + cslice) * 2) = make_float2(smean, ssq);
     }
-    const float ssq = sum4(q2[0] + q2[1]);
-    const int cslice = (n0 >> 6) + wn;
-    if (q4 == 0 && (FULL || (m < g.M && cslice * 64 < g.N)))
-      *reinterpret_cast<float2*>(g.spart + ((size_t)m * (g.N >> 6) + cslice) * 2) = make_float2(smean, ssq);
   }
   if (EPI != GE_F32) {
     // widen the stores: v_permlane16_swap exchanges the odd 16-lane rows of tile a with the even rows of tile

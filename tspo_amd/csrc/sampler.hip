@@ -250,6 +250,17 @@ __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
   __shared__ float red[32];
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* l = logits + (size_t)b * T;
+  if (g == G) {   // the extra workgroup of prompt b: log(softmax(logits)) - no noise (model/utils.py:78).  Its own workgroup since
+                  // round 5 (rollout 0's workgroup did it after its selection: the longest chain of the launch, 8.8 -> 7 us)
+    float lmax = -INFINITY;
+    for (int t = tid; t < T; t += SEL_THREADS) lmax = fmaxf(lmax, l[t]);
+    lmax = block_max(lmax, red);
+    float se = 0.f;
+    for (int t = tid; t < T; t += SEL_THREADS) se += expf(l[t] - lmax);
+    se = block_sum(se, red);
+    for (int t = tid; t < T; t += SEL_THREADS) logp[(size_t)b * T + t] = logf(expf(l[t] - lmax) / se);
+    return;
+  }
   const size_t row = ((size_t)b * G + g) * T;
   float* zbuf = reinterpret_cast<float*>(lds_keys + (LONG ? 0 : T));
   // per_offset = p > 0: prompts come in groups of p that would have been separate calls (micro-steps of one optimizer step):
@@ -261,18 +272,16 @@ __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
     return noise ? noise[row + t] : gumbel_from_bits(philox_x0((uint32_t)t, (uint32_t)g, cb, off_lo, key0, key1));
   };
   auto zf = [&](int t) { return (l[t] + gnoise(t)) / tau; };
-  float zmax = -INFINITY, lmax = -INFINITY;
+  float zmax = -INFINITY;
   for (int t = tid; t < T; t += SEL_THREADS) {
     const float gn = gnoise(t);
     if (noise_out) noise_out[row + t] = gn;
-    const float lv = l[t];
-    const float z = (lv + gn) / tau;
+    const float z = (l[t] + gn) / tau;
     if (!LONG) {
       lds_keys[t] = order_key(z);
       if (probs) zbuf[t] = z;
     }
     zmax = fmaxf(zmax, z);
-    lmax = fmaxf(lmax, lv);
   }
   __syncthreads();
   if (LONG) {
@@ -282,13 +291,6 @@ __global__ __launch_bounds__(SEL_THREADS) void gumbel_topk_kernel(
     select_topk_sorted([kp](int t) { return kp[t]; }, T, k, idx + ((size_t)b * G + g) * k, sh);
   }
 
-  if (logp && g == 0) {  // log(softmax(logits)) - no noise (model/utils.py:78)
-    lmax = block_max(lmax, red);
-    float se = 0.f;
-    for (int t = tid; t < T; t += SEL_THREADS) se += expf(l[t] - lmax);
-    se = block_sum(se, red);
-    for (int t = tid; t < T; t += SEL_THREADS) logp[(size_t)b * T + t] = logf(expf(l[t] - lmax) / se);
-  }
   if (probs) {  // (one_hot - y) + y with y = softmax(z)  (model/utils.py:74-75)
     zmax = block_max(zmax, red);
     float se = 0.f;
@@ -324,10 +326,10 @@ extern "C" int tspo_gumbel_topk_ex(const float* logits, const float* noise, uint
   const uint32_t key0 = (uint32_t)(seed & 0xFFFFFFFFu), seed_hi = (uint32_t)(seed >> 32);
   if (T <= SEL_LDS_KEYS) {
     const size_t lds = (size_t)T * 4 * (probs ? 2 : 1);
-    hipLaunchKernelGGL(gumbel_topk_kernel<false>, dim3(G, B), dim3(SEL_THREADS), lds, (hipStream_t)stream, logits, noise, key0,
+    hipLaunchKernelGGL(gumbel_topk_kernel<false>, dim3(G + (logp ? 1 : 0), B), dim3(SEL_THREADS), lds, (hipStream_t)stream, logits, noise, key0,
                        seed_hi, offset, prompts_per_offset, G, T, k, tau, idx, logp, probs, noise_out);
   } else {
-    hipLaunchKernelGGL(gumbel_topk_kernel<true>, dim3(G, B), dim3(SEL_THREADS), 0, (hipStream_t)stream, logits, noise, key0,
+    hipLaunchKernelGGL(gumbel_topk_kernel<true>, dim3(G + (logp ? 1 : 0), B), dim3(SEL_THREADS), 0, (hipStream_t)stream, logits, noise, key0,
                        seed_hi, offset, prompts_per_offset, G, T, k, tau, idx, logp, probs, noise_out);
   }
   return tspo::check_launch("gumbel_topk");

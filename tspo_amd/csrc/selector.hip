@@ -607,27 +607,41 @@ template <int HD>
 __device__ __forceinline__ void band_scores_T(const float* const (&arow)[2], const float* brow, int q, f32x4 (&acc)[2]) {
   acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
   acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // every operand load of the product first (3 x HD / 16 float4 per lane), then the MFMA chain: the launch is one latency chain
+  // per wave, and the compiler's own schedule kept only a chunk or two in flight
+  f32x4 bf[HD / 16], a0[HD / 16], a1[HD / 16];
 #pragma unroll
   for (int ch = 0; ch < HD / 16; ++ch) {
-    const f32x4 bf = *reinterpret_cast<const f32x4*>(brow + ch * 16 + 4 * q);
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow[0] + ch * 16 + 4 * q);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow[1] + ch * 16 + 4 * q);
+    bf[ch] = *reinterpret_cast<const f32x4*>(brow + ch * 16 + 4 * q);
+    a0[ch] = *reinterpret_cast<const f32x4*>(arow[0] + ch * 16 + 4 * q);
+    a1[ch] = *reinterpret_cast<const f32x4*>(arow[1] + ch * 16 + 4 * q);
+  }
+#pragma unroll
+  for (int ch = 0; ch < HD / 16; ++ch)   // (the values as operands of an empty statement: every request is out before the first MFMA)
+    asm volatile("" : "+v"(bf[ch]), "+v"(a0[ch]), "+v"(a1[ch]));
+#pragma unroll
+  for (int ch = 0; ch < HD / 16; ++ch) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[st], bf[st], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[st], bf[st], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ch][st], bf[ch][st], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ch][st], bf[ch][st], acc[1], 0, 0, 0);
     }
   }
 }
 
-// out[tile] += sum over the 32 tile rows of coef[tt][r] (A: MFMA row l15) x mat[row rb+16tt+4q+r][head cols] (B).
-// `mat` points at the head's first column of row 0 of the video; rows are clamped to [0, T-1] (their coefficient is 0).
+// The 32 rows rb .. rb+31 (clamped to [0, T-1]) of `mat` (head's first column of row 0 of the video) as MFMA B operands: this
+// lane's rows rb + 16 tt + 4 q + r, its 4 (2, 1) columns of every lane-vector group.  Loaded ahead of time (band_rows_load, issued
+// before the score product of the same kernel - the rows do not depend on it) and consumed by band_rows_mma: round 5, the
+// just-in-time loads of the combined form exposed one L2 round trip per row (8 in a row) in each of the three kernels.
 template <int HD>
-__device__ __forceinline__ void band_rows_x_mat(const f32x4 (&coef)[2], const float* mat, size_t ld, int rb, int T, int q,
-                                                int l15, f32x4 (&out)[HD / 16]) {
+struct BandRows {
+  f32x4 v4[8][HeadCols<HD>::N4 > 0 ? HeadCols<HD>::N4 : 1];
+  float2 v2[8];
+  float v1[8];
+};
+template <int HD>
+__device__ __forceinline__ void band_rows_load(const float* mat, size_t ld, int rb, int T, int q, int l15, BandRows<HD>& R) {
   using HC = HeadCols<HD>;
-#pragma unroll
-  for (int c = 0; c < HC::TILES; ++c) out[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -635,22 +649,35 @@ __device__ __forceinline__ void band_rows_x_mat(const f32x4 (&coef)[2], const fl
       int row = rb + 16 * tt + 4 * q + r;
       row = row < 0 ? 0 : (row > T - 1 ? T - 1 : row);
       const float* mr = mat + (size_t)row * ld;
+#pragma unroll
+      for (int g = 0; g < HC::N4; ++g) R.v4[tt * 4 + r][g] = *reinterpret_cast<const f32x4*>(mr + 64 * g + 4 * l15);
+      if (HC::HAS2) R.v2[tt * 4 + r] = *reinterpret_cast<const float2*>(mr + HC::BASE2 + 2 * l15);
+      if (HC::HAS1) R.v1[tt * 4 + r] = mr[HC::BASE1 + l15];
+    }
+}
+// out[tile] = sum over the 32 rows of coef[tt][r] (A: MFMA row l15) x row (B); rows outside [0, T-1] carry coefficient 0.
+template <int HD>
+__device__ __forceinline__ void band_rows_mma(const f32x4 (&coef)[2], const BandRows<HD>& R, f32x4 (&out)[HD / 16]) {
+  using HC = HeadCols<HD>;
+#pragma unroll
+  for (int c = 0; c < HC::TILES; ++c) out[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
       const float cf = coef[tt][r];
 #pragma unroll
       for (int g = 0; g < HC::N4; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(mr + 64 * g + 4 * l15);
+        const f32x4 v = R.v4[tt * 4 + r][g];
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[4 * g + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, v[c], out[4 * g + c], 0, 0, 0);
       }
       if (HC::HAS2) {
-        const float2 v = *reinterpret_cast<const float2*>(mr + HC::BASE2 + 2 * l15);
+        const float2 v = R.v2[tt * 4 + r];
         out[4 * HC::N4] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, v.x, out[4 * HC::N4], 0, 0, 0);
         out[4 * HC::N4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, v.y, out[4 * HC::N4 + 1], 0, 0, 0);
       }
-      if (HC::HAS1) {
-        const float v = mr[HC::BASE1 + l15];
-        out[HC::TILES - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, v, out[HC::TILES - 1], 0, 0, 0);
-      }
+      if (HC::HAS1) out[HC::TILES - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, R.v1[tt * 4 + r], out[HC::TILES - 1], 0, 0, 0);
     }
 }
 
@@ -720,6 +747,9 @@ __global__ __launch_bounds__(256) void band_attn_fwd_mfma_kernel(const float* __
     kr = kr < 0 ? 0 : (kr > T - 1 ? T - 1 : kr);
     arow[tt] = base + (size_t)kr * ld + D;
   }
+  BandRows<HD> vrows;
+  band_rows_load<HD>(base + 2 * D, ld, kb, T, q, l15, vrows);   // the V rows of the second product, requested before the first
+  asm volatile("" ::: "memory");                                 // (keeps the requests here: hipcc sinks them behind the softmax)
   f32x4 sc[2];
   band_scores_T<HD>(arow, base + (size_t)tq * ld, q, sc);
   const float scale = 1.0f / sqrtf((float)HD);
@@ -755,7 +785,7 @@ __global__ __launch_bounds__(256) void band_attn_fwd_mfma_kernel(const float* __
       if (t < T && slot >= 0 && slot < w) P[pair * w + slot] = sc[tt][r];   // slots past the clipped window hold 0
     }
   f32x4 out[HD / 16];
-  band_rows_x_mat<HD>(sc, base + 2 * D, ld, kb, T, q, l15, out);
+  band_rows_mma<HD>(sc, vrows, out);
   band_store_rows<HD>(out, ctx + (size_t)k.b * T * D + k.h * HD, (size_t)D, k.i0, T, q, l15);
 }
 
@@ -780,13 +810,13 @@ __global__ __launch_bounds__(256) void band_attn_bwd_q_mfma_kernel(const float* 
     kr = kr < 0 ? 0 : (kr > T - 1 ? T - 1 : kr);
     arow[tt] = base + (size_t)kr * ld + 2 * D;   // V rows
   }
-  f32x4 dp[2];
-  band_scores_T<HD>(arow, dctx + ((size_t)k.b * T + tq) * D + k.h * HD, q, dp);
+  BandRows<HD> krows;
+  band_rows_load<HD>(base + D, ld, kb, T, q, l15, krows);   // the K rows of dq = dS . K, requested before the first product
+  asm volatile("" ::: "memory");
   const float scale = 1.0f / sqrtf((float)HD);
   const int lo = max(0, tq - w / 2), hi = min(T - 1, tq - w / 2 + w - 1);
   const size_t pair = ((size_t)k.b * T + tq) * H + k.h;
-  f32x4 pv[2];
-  float dot = 0.f;
+  f32x4 pv[2];   // the softmax weights of this lane's (query, key) pairs: requested with the rows, they do not depend on the product
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -794,8 +824,15 @@ __global__ __launch_bounds__(256) void band_attn_bwd_q_mfma_kernel(const float* 
       const int key = kb + 16 * tt + 4 * q + r;
       const bool ok = key >= lo && key <= hi;
       pv[tt][r] = ok ? P[pair * w + (key - lo)] : 0.f;
-      dot += pv[tt][r] * dp[tt][r];
     }
+  __builtin_amdgcn_sched_barrier(0);   // (the requests stay in front of the product; nothing waits for them here)
+  f32x4 dp[2];
+  band_scores_T<HD>(arow, dctx + ((size_t)k.b * T + tq) * D + k.h * HD, q, dp);
+  float dot = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dot += pv[tt][r] * dp[tt][r];
   dot = xor_sum_hi(dot);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
@@ -807,7 +844,7 @@ __global__ __launch_bounds__(256) void band_attn_bwd_q_mfma_kernel(const float* 
       if (t < T && slot >= 0 && slot < w) dS[pair * w + slot] = ds;
     }
   f32x4 out[HD / 16];
-  band_rows_x_mat<HD>(dp, base + D, ld, kb, T, q, l15, out);   // dq = dS . K
+  band_rows_mma<HD>(dp, krows, out);   // dq = dS . K
   band_store_rows<HD>(out, dqkv + (size_t)k.b * T * ld + k.h * HD, ld, k.i0, T, q, l15);
 }
 
@@ -824,6 +861,9 @@ __global__ __launch_bounds__(256) void band_attn_bwd_kv_mfma_kernel(const float*
   const size_t ld = (size_t)3 * D;
   const int j = k.i0 + l15;                       // this lane's key (MFMA row of the coefficient operand)
   const int tb = k.i0 - (w - 1 - w / 2);          // first query of the tile pair: j-(w-1-w/2) <= t <= j+w/2
+  BandRows<HD> qrows, grows;                      // the Q rows (dk) and the dctx rows (dv): requested before the coefficients
+  band_rows_load<HD>(qkv + (size_t)k.b * T * ld + k.h * HD, ld, tb, T, q, l15, qrows);
+  band_rows_load<HD>(dctx + (size_t)k.b * T * D + k.h * HD, (size_t)D, tb, T, q, l15, grows);
   f32x4 cds[2], cp[2];
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
@@ -844,9 +884,9 @@ __global__ __launch_bounds__(256) void band_attn_bwd_kv_mfma_kernel(const float*
     }
   f32x4 out[HD / 16];
   float* dst = dqkv + (size_t)k.b * T * ld + k.h * HD;
-  band_rows_x_mat<HD>(cds, qkv + (size_t)k.b * T * ld + k.h * HD, ld, tb, T, q, l15, out);   // dk = dS^T . Q
+  band_rows_mma<HD>(cds, qrows, out);   // dk = dS^T . Q
   band_store_rows<HD>(out, dst + D, ld, k.i0, T, q, l15);
-  band_rows_x_mat<HD>(cp, dctx + (size_t)k.b * T * D + k.h * HD, (size_t)D, tb, T, q, l15, out);   // dv = P^T . dctx
+  band_rows_mma<HD>(cp, grows, out);   // dv = P^T . dctx
   band_store_rows<HD>(out, dst + 2 * D, ld, k.i0, T, q, l15);
 }
 
@@ -879,7 +919,30 @@ bool band_mfma(int which, const float* qkv, float* ctx, float* P, const float* d
 
 // ---------------------------------------------------------------------------
 // s_t = (mean_m h_t.e_m / (|h_t||e_m| + 1e-6) + clip_t) / tau   (temporal_agent.py:106-114,135-141)
-// one wave per (b,t) row
+// one wave per (b,t) row; 16-byte loads, |h|^2 together with the first text row's dot products in ONE pass over the row (round 5:
+// three dependent passes of 4-byte loads before - the launch is a latency chain, 9.0 -> 5 us at B T = 1024)
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
+// this lane's share of h.h, h.e and e.e over a row of nv float4 (lane + 64 i): the loads of up to 4 chunks of BOTH rows are issued
+// together, then the arithmetic (D <= 1024: one round trip per row)
+__device__ __forceinline__ void row_dots(const f32x4* __restrict__ hr, const f32x4* __restrict__ er, int nv, int lane, bool want_hh,
+                                         float& hh, float& de, float& ee) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = lane; c0 < nv; c0 += 256) {
+    f32x4 hv[4], ev[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + 64 * i;
+      hv[i] = c < nv ? hr[c] : z;
+      ev[i] = c < nv ? er[c] : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (want_hh) hh += dot4(hv[i], hv[i]);
+      de += dot4(hv[i], ev[i]);
+      ee += dot4(ev[i], ev[i]);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict__ h, const float* __restrict__ txt,
                                                         const float* __restrict__ clip, float* __restrict__ scores,
                                                         int B, int T, int D, int M, float tau) {
@@ -887,19 +950,14 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict_
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * T) return;
   const int b = (int)(row / T);
-  const float* hr = h + row * D;
-  float hh = 0.f;
-  for (int d = lane; d < D; d += 64) hh += hr[d] * hr[d];
-  const float hn = sqrtf(wave_sum(hh));
-  float acc = 0.f;
+  const f32x4* hr = reinterpret_cast<const f32x4*>(h + row * D);
+  const int nv = D >> 2;   // D % 64 == 0
+  float hh = 0.f, acc = 0.f, hn = 0.f;
   for (int m = 0; m < M; ++m) {
-    const float* er = txt + ((size_t)b * M + m) * D;
+    const f32x4* er = reinterpret_cast<const f32x4*>(txt + ((size_t)b * M + m) * D);
     float de = 0.f, ee = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      const float e = er[d];
-      de += hr[d] * e;
-      ee += e * e;
-    }
+    row_dots(hr, er, nv, lane, m == 0, hh, de, ee);
+    if (m == 0) hn = sqrtf(wave_sum(hh));
     de = wave_sum(de);
     const float en = sqrtf(wave_sum(ee));
     acc += de / (hn * en + 1e-6f);
@@ -949,9 +1007,12 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * T) return;
   const int b = (int)(row / T);
-  const float* hr = h + row * D;
-  float hh = 0.f;
-  for (int d = lane; d < D; d += 64) hh += hr[d] * hr[d];
+  // 16-byte loads / stores; |h|^2 and the first text row's products in one pass; dh written once (M = 1: no read-modify-write)
+  const f32x4* hr = reinterpret_cast<const f32x4*>(h + row * D);
+  f32x4* dr = reinterpret_cast<f32x4*>(dh + row * D);
+  const int nv = D >> 2;
+  float hh = 0.f, de0 = 0.f, ee0 = 0.f;
+  row_dots(hr, reinterpret_cast<const f32x4*>(txt + (size_t)b * M * D), nv, lane, true, hh, de0, ee0);
   const float hn = sqrtf(wave_sum(hh));
   float ds;
   if (PG) {   // G <= 64: lane g owns rollout g of this row's prompt
@@ -991,21 +1052,35 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
     ds = dscores[row];
   }
   const float g = ds / tau / (float)M;
-  for (int d = lane; d < D; d += 64) dh[row * D + d] = 0.f;
   for (int m = 0; m < M; ++m) {
-    const float* er = txt + ((size_t)b * M + m) * D;
-    float de = 0.f, ee = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      const float e = er[d];
-      de += hr[d] * e;
-      ee += e * e;
+    const f32x4* er = reinterpret_cast<const f32x4*>(txt + ((size_t)b * M + m) * D);
+    float de = de0, ee = ee0;
+    if (m > 0) {
+      float unused = 0.f;
+      de = 0.f; ee = 0.f;
+      row_dots(hr, er, nv, lane, false, unused, de, ee);
     }
     de = wave_sum(de);
     const float en = sqrtf(wave_sum(ee));
     const float den = hn * en + 1e-6f;
     const float ca = g / den;
     const float cb = hn > 0.f ? g * de * en / (den * den * hn) : 0.f;
-    for (int d = lane; d < D; d += 64) dh[row * D + d] += ca * er[d] - cb * hr[d];
+    for (int c0 = lane; c0 < nv; c0 += 256) {   // (h and e are L1 / L2 hits by now; all loads of a round first)
+      f32x4 hv[4], ev[4], dv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c0 + 64 * i;
+        if (c < nv) { hv[i] = hr[c]; ev[i] = er[c]; if (m > 0) dv[i] = dr[c]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c0 + 64 * i;
+        if (c < nv) {
+          const f32x4 v = ca * ev[i] - cb * hv[i];
+          dr[c] = m == 0 ? v : dv[i] + v;
+        }
+      }
+    }
   }
 }
 
