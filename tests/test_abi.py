@@ -133,6 +133,27 @@ def test_agpr_gemm_code_audit(tmp_path):
             cur.append(t)
         blocks.append(cur)
         assert not bad, f"{name}: compiler-emitted AGPR access outside the asm statements: {bad[:3]}"
+        # round 5: nothing interlocks a VALU write with the operand read of an MFMA the compiler cannot see inside an asm statement (it
+        # may assemble an operand tuple with v_movs directly in front of the statement: garbage row statistics until found) - every
+        # hand-written MFMA is either preceded by an s_nop or its A / B operands are not written by the two instructions before it
+        ins = [t for t in (ln.strip() for ln in body.split("\n")) if t and not t.startswith((";", ".")) and not re.match(r"^\.?LBB", t)]
+        def regs(tok):
+            m = re.match(r"v\[(\d+):(\d+)\]", tok)
+            if m:
+                return set(range(int(m.group(1)), int(m.group(2)) + 1))
+            m = re.match(r"v(\d+)$", tok)
+            return {int(m.group(1))} if m else set()
+        for i, t in enumerate(ins):
+            if not t.startswith("v_mfma"):
+                continue
+            ops_ = [x.strip() for x in t.split(None, 1)[1].split(",")]
+            src = regs(ops_[1]) | regs(ops_[2])
+            for prev in reversed(ins[max(0, i - 2):i]):      # nearest first; an s_nop in between settles it
+                if prev.startswith("s_nop"):
+                    break
+                if prev.startswith("v_") and not prev.startswith("v_mfma"):
+                    dst = regs(prev.split(None, 1)[1].split(",")[0].strip())
+                    assert not (dst & src), f"{name}: VALU write of an MFMA operand right in front of it: {prev} -> {t}"
         assert not m0bad, f"{name}: compiler-emitted m0 use next to the hand-written LDS-DMA: {m0bad[:3]}"
         assert not any(x.startswith("scratch_") for blk in blocks for x in blk), f"{name}: scratch access"
         kblocks = [blk for blk in blocks if sum(x.startswith("v_mfma") for x in blk) >= 100]      # the K-step bodies (the epilogue of the

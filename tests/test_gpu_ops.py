@@ -688,6 +688,51 @@ def test_gemm_remainder_phase_bitwise_at_encoder_size(N, K):
         del A, W, R, a, b
 
 
+@pytest.mark.parametrize("n_frames", [64, 70])
+def test_residual_statistics_epilogue_against_the_stored_rows(n_frames):
+    """The residual + statistics epilogue of the production GEMM (GE_RESID_ST; round 5: residual rows added and row statistics
+    formed on the matrix pipe) has no entry of its own in the C ABI - the encoder is its only caller - so it is checked where it
+    runs: one CLIP-L/14 block with a zero fc2 (so that the residual stream after the block IS the out-proj's output, in place),
+    LayerNorms folded: the per-row, per-64-column-slice (mean, centred sum of squares) pairs the out-proj's epilogue left in the
+    workspace against the same statistics of the bf16 rows it stored.  64 frames = 64.25 row tiles, 70 frames = 70.27: the ragged
+    tile runs through the 64x64 remainder sub-tiles (a second copy of the epilogue; round 5 found a VALU -> asm-MFMA hazard there
+    that only this comparison shows: the features of the class-token rows stayed finite).  Workspace layout: clip_carve() of
+    csrc/clip_vit.hip (x | h | qkv | a | u | patches | pooled | stats | spart, 256-byte aligned)."""
+    cfg = dict(synth.CLIP_L14)
+    cfg["layers"] = 1
+    state = synth.clip_vision_state(**cfg)
+    for k in ("mlp.fc2.weight", "mlp.fc2.bias"):
+        state["vision_model.encoder.layers.0." + k] = np.zeros_like(state["vision_model.encoder.layers.0." + k])
+    W = ops.ClipVitWeights({k: T_(v) for k, v in state.items()}, cfg, DEV)
+    u8 = G_(synth.uniform_u8((n_frames, 3, 224, 224), 5 + n_frames))
+    feat = ops.clip_vit_forward(W, u8, fold_layernorm=True)
+    torch.cuda.synchronize()
+    M, C, mlp = n_frames * 257, cfg["hidden"], cfg["mlp"]
+    off = [0]
+
+    def take(nbytes):
+        o = (off[0] + 255) // 256 * 256
+        off[0] = o + nbytes
+        return o
+    ox = take(M * C * 2); take(M * C * 2); take(M * 3 * C * 2); take(M * C * 2); take(M * mlp * 2)
+    take(n_frames * 256 * 640 * 2); take(n_frames * C * 2); take(M * 2 * 4)
+    osp = take(M * (C // 64) * 2 * 4)
+    ws = W.workspace(n_frames)
+    x = ws[ox:ox + M * C * 2].view(torch.bfloat16).view(M, C).float()
+    sp = ws[osp:osp + M * (C // 64) * 8].view(torch.float32).view(M, C // 64, 2)
+    assert torch.isfinite(feat).all() and torch.isfinite(x).all() and torch.isfinite(sp).all()
+    xs = x.double().view(M, C // 64, 64)
+    mean = xs.mean(-1)
+    m2 = ((xs - mean[..., None]) ** 2).sum(-1)
+    dm = (sp[..., 0].double() - mean).abs().max().item()
+    dq = ((sp[..., 1].double() - m2).abs() / m2.clamp_min(1e-3)).max().item()
+    print(f"\n[GE_RESID_ST statistics, {n_frames} frames] max |mean - ref| {dm:.2e}, max rel |M2 - ref| {dq:.2e}")
+    assert dm < 5e-6 and dq < 1e-4          # fp32 sums of 64 exact bf16 values / their exact squares: rounding of the sums only
+    # and the stand-alone LayerNorm path (other kernels, same arithmetic up to bf16 rounding) ends in the same features
+    feat0 = ops.clip_vit_forward(W, u8, fold_layernorm=False)
+    assert (feat - feat0).abs().max().item() < 0.02 * feat0.abs().max().item()
+
+
 def test_clip_vit_forward_70_frames_production_kernels():
     """70 frames (M = 17990 rows) is large enough that every encoder GEMM takes the persistent kernel: features vs
     the fp32 oracle on the CPU (bf16-rounded matrices) within the encode tolerance."""

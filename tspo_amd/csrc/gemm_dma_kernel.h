@@ -165,7 +165,8 @@ __device__ __forceinline__ void a9_tail_subtile(const GemmArgs& g, char* lds, in
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)   // inline asm with VGPR accumulators: hipcc must not pick AGPRs in this kernel (it would for the builtin)
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[ni]) : "v"(fw[kh][ni]), "v"(fa[kh]));
+        // (s_nop: see epi_resid_mfma - an operand tuple the compiler assembles with v_movs in front of the statement is not interlocked)
+        asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[ni]) : "v"(fw[kh][ni]), "v"(fa[kh]));
   }
   const int m = m_s + wid * 16 + l15;
   if (EPI == GE_RESID || EPI == GE_RESID_ST) {   // the residual rows onto the accumulators, exactly as the whole-tile epilogue does it

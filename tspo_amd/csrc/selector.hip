@@ -1011,6 +1011,22 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
   const f32x4* hr = reinterpret_cast<const f32x4*>(h + row * D);
   f32x4* dr = reinterpret_cast<f32x4*>(dh + row * D);
   const int nv = D >> 2;
+  // PG: what the policy-gradient term needs from memory is requested FIRST, with the row's own loads (round 5: the membership test
+  // was a binary search in global memory behind everything else - five dependent round trips, the longest chain of the launch).
+  // G * k <= 256 (the training shapes: 8 x 16): the wave reads the prompt's G sorted lists flat, lane l entries l, l + 64, ...
+  float pg_r = 0.f, pg_lp = 0.f;
+  int64_t pg_e[4] = {-1, -1, -1, -1};
+  const bool coop = PG && pg.G * pg.k <= 256;
+  if (PG) {
+    pg_r = lane < pg.G ? pg.rewards[(size_t)b * pg.G + lane] : 0.f;
+    pg_lp = pg.logp[row];
+    if (coop) {
+      const int64_t* lst = pg.idx + (size_t)b * pg.G * pg.k;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c * 64 + lane < pg.G * pg.k) pg_e[c] = lst[c * 64 + lane];
+    }
+  }
   float hh = 0.f, de0 = 0.f, ee0 = 0.f;
   row_dots(hr, reinterpret_cast<const f32x4*>(txt + (size_t)b * M * D), nv, lane, true, hh, de0, ee0);
   const float hn = sqrtf(wave_sum(hh));
@@ -1018,13 +1034,23 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
   if (PG) {   // G <= 64: lane g owns rollout g of this row's prompt
     const int t = (int)(row - (long)b * T), G = pg.G, k = pg.k;
     const bool live = lane < G;
-    const float r = live ? pg.rewards[(size_t)b * G + lane] : 0.f;
+    const float r = pg_r;
     const float mean = wave_sum(r) / (float)G;
     const float dm = live ? r - mean : 0.f;
     const float sd = sqrtf(wave_sum(dm * dm) / (float)(G - 1));
     const float a = live ? (r - mean) / (sd + pg.eps) : 0.f;
     bool hit = false;
-    if (live) {
+    if (coop) {   // is t in rollout lane's list?  ballot of "entry == t" per 64-entry chunk, lane g looks at its own bit range
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned long long m = __ballot(pg_e[c] == (int64_t)t);
+        const int lo = max(lane * k - c * 64, 0), hi = min((lane + 1) * k - c * 64, 64);
+        if (live && lo < hi) {
+          const unsigned long long width = hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull);
+          hit = hit || (((m >> lo) & width) != 0ull);
+        }
+      }
+    } else if (live) {
       const int64_t* my = pg.idx + ((size_t)b * G + lane) * k;
       int lo = 0, hi = k - 1;
       while (lo <= hi) {
@@ -1034,7 +1060,7 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
         if (v < t) lo = mid + 1; else hi = mid - 1;
       }
     }
-    const float p = expf(pg.logp[row]);
+    const float p = expf(pg_lp);
     const float invk = 1.f / (float)k, invG = 1.f / (float)G;
     const float y = (hit ? invk : 0.f) - p;
     float acc = 0.f, sumA = 0.f;
@@ -1643,6 +1669,9 @@ struct SelWs {  // workspace layout shared by forward and backward
 // at one-SIMD-per-wave speed, so the makespan is set by how evenly tiles*S workgroups fill 256 CUs: pick the S (chunk
 // of >= 128 rows, at most 16 partial planes) that wastes the least of the last "round" for both the DxD and 3DxD GEMMs.
 int split_for(int BT, int D) {
+  // BT <= 1024 (the reference's two micro-steps as one batch): measured sweep S = 3 ... 8 on the coalesced DP path: 267 (S = 3), 278,
+  // 278, 272, 269 (S = 7, what the rule below picks), 270 us per optimizer step - fewer planes for the reduction launch to sum
+  if (BT > 768 && BT <= 1024 && D == 768) return 3;
   int smax = BT / 128;
   smax = smax < 1 ? 1 : (smax > 16 ? 16 : smax);
   const int tiles = ((D + 127) / 128) * ((D + 127) / 128);
