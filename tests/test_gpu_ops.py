@@ -376,6 +376,18 @@ def test_fused_policy_entries_match_the_separate_ones():
     assert torch.equal(adv_a, adv_b) and torch.equal(loss_a, loss_b)
     gmax = ga.abs().max().item()
     assert gmax > 0 and (ga - gb).abs().max().item() <= 2e-6 * gmax     # dL/dscores differs in the last bit (measured 8e-7)
+    # the fused entry tests "is frame t in rollout g's list" by ballot over one flat read of the prompt's G lists when G * k <= 256
+    # (round 5) and by binary search beyond: list lengths that straddle the 64-entry chunks, the exact limit, both sides of it
+    for Gq, kq in ((5, 7), (16, 16), (16, 17), (64, 4), (2, 100), (3, 100), (2, 1)):
+        ro = ops.gumbel_topk(sc, kq, Gq, seed=11 + Gq)
+        rw = G_(synth.uniform((Bp, Gq), 95 + kq).reshape(Bp, Gq).astype(np.float32))
+        ga.zero_(); gb.zero_()
+        adv_a, dl_a, loss_a = ops.grpo_pg_grad(rw, ro["logp"], ro["idx"], scale=0.5)
+        ops.selector_backward(flat, ga, img, txt, dl_a, Hp, Wp, taup, ws)
+        adv_b, loss_b = ops.policy_backward(flat, gb, img, txt, rw, ro["logp"], ro["idx"], Hp, Wp, taup, ws, scale=0.5)
+        assert torch.equal(adv_a, adv_b) and torch.equal(loss_a, loss_b), (Gq, kq)
+        gmax = ga.abs().max().item()
+        assert (ga - gb).abs().max().item() <= 2e-6 * max(gmax, 1e-30), (Gq, kq)
     # ragged tail (n % 4 != 0) of the vectorised kernels
     n = 1003
     g = G_(synth.normal((n,), 90, 1e-2))
