@@ -545,6 +545,14 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
                                                          float max_norm, float* __restrict__ out2) {
   __shared__ float red[32];
   __shared__ float gs_sh;
+  // this thread's first element group is requested BEFORE the norm reduction (it does not depend on it): the reduction's two
+  // barriers and its serial tail used to run with nothing in flight (round 5; same arithmetic, same results)
+  const size_t n4 = n >> 2;
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool has0 = i0 < n4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 g0 = has0 ? reinterpret_cast<const f32x4*>(g)[i0] : z4, p0 = has0 ? reinterpret_cast<f32x4*>(p)[i0] : z4;
+  const f32x4 m0 = has0 ? reinterpret_cast<f32x4*>(m)[i0] : z4, v0 = has0 ? reinterpret_cast<f32x4*>(v)[i0] : z4;
   float s = 0.f;
   for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
   s = block_sum(s, red);
@@ -558,11 +566,9 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
   __syncthreads();
   const float gs = gs_sh;
   const float step_size = lr / bc1;
-  const size_t n4 = n >> 2;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i] * gs;
-    f32x4 p4 = reinterpret_cast<f32x4*>(p)[i] * (1.f - lr * wd);
-    f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+  auto upd = [&](size_t i, f32x4 g4, f32x4 p4, f32x4 m4, f32x4 v4) {
+    g4 = g4 * gs;
+    p4 = p4 * (1.f - lr * wd);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       m4[c] = b1 * m4[c] + (1.f - b1) * g4[c];
@@ -572,7 +578,11 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
     reinterpret_cast<f32x4*>(p)[i] = p4;
     reinterpret_cast<f32x4*>(m)[i] = m4;
     reinterpret_cast<f32x4*>(v)[i] = v4;
-  }
+  };
+  if (has0) upd(i0, g0, p0, m0, v0);
+  for (size_t i = i0 + (size_t)gridDim.x * 256; i < n4; i += (size_t)gridDim.x * 256)
+    upd(i, reinterpret_cast<const f32x4*>(g)[i], reinterpret_cast<f32x4*>(p)[i], reinterpret_cast<f32x4*>(m)[i],
+        reinterpret_cast<f32x4*>(v)[i]);
   for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float gi = g[i] * gs;
     float pi = p[i] * (1.f - lr * wd);
