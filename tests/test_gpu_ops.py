@@ -646,6 +646,24 @@ def test_gemm_bf16_persistent_kernel_full_check(N, K):
         np.testing.assert_allclose(out.numpy(), want.numpy(), err_msg=f"variant {variant}", **tol)
 
 
+@pytest.mark.parametrize("N,K", [(1024, 1024), (1024, 4096)], ids=["out", "fc2"])
+def test_gemm_residual_in_place_equals_out_of_place(N, K):
+    """The encoder's out-proj / fc2 add the residual stream IN PLACE (R == C).  Since round 5 the residual rows of a tile's first
+    64-column slice are requested from inside the tile's last K-step and the second slice's as the first slice's row blocks are
+    consumed - every request of an element has to stay in front of that element's store: in place == out of place, bit for bit, on
+    70 frames (M = 17 990: whole tiles, a ragged last row tile, and the 64x64 remainder sub-tiles) and on 40 (no remainder phase)."""
+    for frames in (70, 40):
+        M = 257 * frames
+        A, W = _bf16r(synth.normal((M, K), 31 + N)), _bf16r(synth.normal((N, K), 32 + K, 0.03))
+        bias, R = T_(synth.normal((N,), 33, 0.1)), _bf16r(synth.normal((M, N), 34))
+        Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
+        for variant in (77, 83):
+            ref = ops.gemm_bf16(Ad, Wd, bias=bd, residual=R.to(DEV), act=variant << 8)
+            x = R.to(DEV).clone()
+            got = ops.gemm_bf16(Ad, Wd, bias=bd, residual=x, act=variant << 8, out=x)
+            assert got.data_ptr() == x.data_ptr() and torch.equal(got, ref), (frames, variant)
+
+
 @pytest.mark.parametrize("M,N,K", [(70001, 264, 128), (20011, 1000, 192), (9000, 3000, 320), (66000, 256, 640), (5000, 4096, 128)],
                          ids=["ragged-N264-K128", "ragged-N1000-K192", "N3000-K320", "N256-K640", "N4096-K128"])
 def test_gemm_dma_kernel_edge_shapes(M, N, K):

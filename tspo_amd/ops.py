@@ -457,14 +457,19 @@ def clip_scores(txt: torch.Tensor, feat: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gemm_bf16(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, act: int = 0, out_f32: bool = False):
-    """C = A @ W^T (+bias)(+residual | quick_gelu): the encoder's MFMA GEMM, exposed for tests / microbenchmarks."""
+def gemm_bf16(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, act: int = 0, out_f32: bool = False,
+              out: Optional[torch.Tensor] = None):
+    """C = A @ W^T (+bias)(+residual | quick_gelu): the encoder's MFMA GEMM, exposed for tests / microbenchmarks.
+    out: write into this [M, N] tensor; it may BE the residual (the encoder's out-proj / fc2 update the residual stream in place)."""
     _need_gpu(A, W, bias, residual)
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
     A, W = A.contiguous(), W.contiguous()
     M, K = A.shape
     N = W.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=A.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=A.device)
+    elif out.shape != (M, N) or out.dtype != (torch.float32 if out_f32 else torch.bfloat16) or not out.is_contiguous():
+        raise ValueError("gemm_bf16: out must be a contiguous [M, N] tensor of the output dtype")
     b = _f32c(bias) if bias is not None else None
     r = residual.contiguous() if residual is not None else None
     check(_lib.lib().tspo_gemm_bf16(_ptr(A), _ptr(W), _ptr(b), _ptr(r), _ptr(out), TSPO_F32 if out_f32 else TSPO_BF16,
