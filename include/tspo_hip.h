@@ -358,7 +358,8 @@ int tspo_clip_scores(const float* txt, const float* feat, int B, int T, int D, i
 
 /* Generic bf16 MFMA GEMM exposed for tests / micro-benchmarks:
  * C[M,N] = A[M,K] * W[N,K]^T (+bias[N]) ; bf16 in, f32 accumulate, out bf16 or f32.
- * K % 64 == 0.  act (bits 0-7): 0 none, 1 quick_gelu.  residual (bf16 [M,N], nullable) is added.
+ * K % 64 == 0.  act (bits 0-7): 0 none, 1 quick_gelu.  residual (bf16 [M,N], nullable) is added; it may alias C (the encoder's
+ * out-proj / fc2 update the residual stream in place: every read of an element precedes its store).
  * Bits 8+ of `act` choose the kernel: 0 = automatic (what the encoder uses: 77 for big shapes, else 1), 1 = small-problem
  * 128x128 kernel, 77 = persistent 256x256 kernel with LDS-DMA operands (whole rounds of whole tiles + the 64x64 remainder
  * phase), 83 = the same kernel with the remainder phase off (a partial last round of whole tiles; bit-identical with 77).
