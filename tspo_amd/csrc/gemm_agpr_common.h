@@ -80,8 +80,8 @@ __device__ __forceinline__ void epi_prefetch_rows(const GemmArgs& g, int m0, int
 }
 
 // The residual tile of the wave comes in 16-byte loads in the STORE mapping (4 lanes cover 64 contiguous bytes of a row) through
-// a ring of 8 x 2 registers.  Slice 0's eight row blocks are requested from INSIDE the tile's last K-step (round 5; epi_rload_rb is
-// called from the gaps behind its last barrier): the K-half-0 fragment registers are dead there, so the 64 ring registers cost
+// a ring of 8 x 2 registers.  Slice 0's eight row blocks are requested from INSIDE the tile's last K-step (round 5; epi_rload is
+// called from the gaps behind its last barrier, one 16-byte load per gap that holds no DMA): the K-half-0 fragment registers are dead there, so the 64 ring registers cost
 // nothing, and the first-touch latency of the residual rows (HBM: the residual stream of a whole video fits no cache) runs behind
 // the last 40 MFMAs instead of in front of the epilogue.  Buffer loads: one descriptor per tile (origin = the tile's first
 // element, range = to the end of the matrix, so rows past M read 0 without a predicate), one per-lane byte offset for the whole
