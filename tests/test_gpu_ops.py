@@ -718,6 +718,24 @@ def test_gemm_remainder_phase_bitwise_at_encoder_size(N, K):
         del A, W, R, a, b
 
 
+def test_patch_gather_u8_staged_kernel_equals_the_generic_one():
+    """CLIP-L/14 on uint8 frames takes the LDS-staged patch gather (coalesced 16-byte loads, round 5) when the frame buffer is
+    16-byte aligned and the generic byte-granular kernel otherwise: the same pixels at a misaligned address must give bitwise the
+    same features (2 layers, 5 frames - the gather is the only kernel whose choice depends on the address)."""
+    cfg = dict(synth.CLIP_L14)
+    cfg["layers"] = 2
+    W = ops.ClipVitWeights({k: T_(v) for k, v in synth.clip_vision_state(**cfg).items()}, cfg, DEV)
+    n = 5
+    u8 = G_(synth.uniform_u8((n, 3, 224, 224), 77))
+    buf = torch.empty(u8.numel() + 16, dtype=torch.uint8, device=DEV)
+    mis = buf[1:1 + u8.numel()].view_as(u8)
+    mis.copy_(u8)
+    assert u8.data_ptr() % 16 == 0 and mis.data_ptr() % 16 == 1
+    fa = ops.clip_vit_forward(W, u8)
+    fb = ops.clip_vit_forward(W, mis)
+    assert torch.isfinite(fa).all() and torch.equal(fa, fb)
+
+
 @pytest.mark.parametrize("n_frames", [64, 70])
 def test_residual_statistics_epilogue_against_the_stored_rows(n_frames):
     """The residual + statistics epilogue of the production GEMM (GE_RESID_ST; round 5: residual rows added and row statistics

@@ -128,6 +128,57 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const TP* __restrict_
 }
 
 // x[n*S + 0][:] = pos_emb[0][:]  (class_embedding already folded into row 0)
+// CLIP-L/14 on uint8 frames (the production front end): one workgroup per (frame, row of 16 patches).  The 3 x 14 image rows that
+// row of patches covers are 42 contiguous 224-byte runs - 588 16-byte loads, every byte of the frame read exactly once, coalesced -
+// staged through LDS; every thread then assembles five 8-value pieces of the 16 patch rows (k = c 196 + ky 14 + kx, zero beyond 588)
+// from LDS bytes through a 3 x 256 table of load_pixel<uint8_t> (the same arithmetic, evaluated once per byte value) and stores them as 16 bytes.  (Round 5: the generic kernel above reads its
+// eight pixels with eight 1-byte global loads at a 14-byte patch pitch: 0.33 ms per 1024 frames = 1.5 TB/s of input + output.)
+__global__ __launch_bounds__(256) void patch_gather_u8_l14_kernel(const uint8_t* __restrict__ px, bf16_t* __restrict__ out) {
+  constexpr int IMG = 224, PATCH = 14, GW = 16, KP = 640, KREAL = 588, ROWB = 224;
+  __shared__ __attribute__((aligned(16))) uint8_t img[3 * PATCH * ROWB];   // [c][ky][224]
+  __shared__ float lut[3][256];   // load_pixel<uint8_t> of every byte value per channel (two IEEE divisions each: once per workgroup, not per pixel)
+  const int py = blockIdx.x;
+  const size_t n = blockIdx.y;
+  const int tid = threadIdx.x;
+  {
+    const uint8_t b = (uint8_t)tid;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lut[c][tid] = load_pixel<uint8_t>(&b, 0, c);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int id = tid + j * 256;   // 16-byte chunk: (c, ky, x16)
+    if (id < 3 * PATCH * (ROWB / 16)) {
+      const int c = id / (PATCH * (ROWB / 16)), rem = id - c * (PATCH * (ROWB / 16));
+      const int ky = rem / (ROWB / 16), x16 = rem - ky * (ROWB / 16);
+      const size_t src = ((n * 3 + c) * IMG + (size_t)(py * PATCH + ky)) * IMG + x16 * 16;
+      *reinterpret_cast<uint4*>(img + id * 16) = *reinterpret_cast<const uint4*>(px + src);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int q = tid + j * 256;    // (patch, 8-value piece): 16 x 80
+    const int pxx = q / (KP / 8), o8 = q - pxx * (KP / 8);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = o8 * 8 + i;
+      if (k < KREAL) {
+        const int c = k / (PATCH * PATCH), rem = k - c * (PATCH * PATCH);
+        const int ky = rem / PATCH, kx = rem - ky * PATCH;
+        v[i] = lut[c][img[(c * PATCH + ky) * ROWB + pxx * PATCH + kx]];
+      } else {
+        v[i] = 0.f;
+      }
+    }
+    uint4 u;
+    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+    u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(out + ((n * (GW * GW) + (size_t)(py * GW + pxx)) * KP + (size_t)o8 * 8)) = u;
+  }
+}
+
 __global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__ pos, bf16_t* __restrict__ x, int n_frames,
                                                        int S, int C) {
   const size_t total = (size_t)n_frames * C;
@@ -1025,7 +1076,9 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       case TSPO_BF16: hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
       case TSPO_F16: hipLaunchKernelGGL(patch_gather_kernel<_Float16>, dim3(nb), dim3(256), 0, st, (const _Float16*)pixels, b.patches, n_frames, c.image, c.patch, Kp); break;
       case TSPO_U8:
-        if (c.image == 224 && c.patch == 14 && Kp == 640)
+        if (c.image == 224 && c.patch == 14 && Kp == 640 && ((uintptr_t)pixels & 15) == 0)
+          hipLaunchKernelGGL(patch_gather_u8_l14_kernel, dim3(16, n_frames), dim3(256), 0, st, (const uint8_t*)pixels, b.patches);
+        else if (c.image == 224 && c.patch == 14 && Kp == 640)
           hipLaunchKernelGGL((patch_gather_kernel<uint8_t, 224, 14, 640>), dim3(nb), dim3(256), 0, st, (const uint8_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp);
         else
           hipLaunchKernelGGL(patch_gather_kernel<uint8_t>, dim3(nb), dim3(256), 0, st, (const uint8_t*)pixels, b.patches, n_frames, c.image, c.patch, Kp);
