@@ -307,9 +307,14 @@ int tspo_clip_vit_forward(const tspo_clip_weights* w, const void* pixels, int pi
  *   TSPO_CLIP_PRUNE_LAST  evaluate the LAST transformer block for the class-token row only - get_image_features
  *                         pools token 0, the other 256 token rows of that block have no consumer; same features up
  *                         to the different GEMM kernel of the small [n_frames, C] matrices (opt-in, off by default:
- *                         the default executes the full model like the reference).                            */
+ *                         the default executes the full model like the reference);
+ *   TSPO_CLIP_FOLD_CACHED the LayerNorm-folded weights of all layers (kept at the front of the workspace, at offsets that do
+ *                         not depend on n_frames) were written by an EARLIER call on this workspace with these weights, on this
+ *                         stream or one ordered before it: the 2 x layers fold launches are skipped.  The library keeps no state -
+ *                         the caller vouches; a call without the flag (re)writes them.  Ignored where nothing is folded.  */
 #define TSPO_CLIP_NO_LN_FOLD 1
 #define TSPO_CLIP_PRUNE_LAST 2
+#define TSPO_CLIP_FOLD_CACHED 4
 int tspo_clip_vit_forward_ex(const tspo_clip_weights* w, const void* pixels, int pixel_dtype, int n_frames,
                              float* feat, void* workspace, size_t workspace_bytes, tspo_stream_t stream, int flags);
 

@@ -718,6 +718,36 @@ def test_gemm_remainder_phase_bitwise_at_encoder_size(N, K):
         del A, W, R, a, b
 
 
+def test_folded_weights_stay_in_the_workspace_between_calls():
+    """Round 5: the LayerNorm-folded weights of all layers are kept at the front of the encoder workspace and the second and later
+    encodes of the same ClipVitWeights on the same workspace skip the 2 x layers fold launches (TSPO_CLIP_FOLD_CACHED): the cached
+    call is bitwise the uncached one, a changed batch size / a new workspace / invalidate_fold_cache() fold again, and the
+    stand-alone LayerNorm path in between leaves the kept weights alone."""
+    cfg = dict(synth.CLIP_L14)
+    cfg["layers"] = 2
+    W = ops.ClipVitWeights({k: T_(v) for k, v in synth.clip_vision_state(**cfg).items()}, cfg, DEV)
+    u8 = G_(synth.uniform_u8((64, 3, 224, 224), 78))
+    assert W._fold_key is None
+    f1 = ops.clip_vit_forward(W, u8)                      # folds
+    key = W._fold_key
+    assert key is not None
+    f2 = ops.clip_vit_forward(W, u8)                      # cached
+    assert W._fold_key == key and torch.equal(f1, f2)
+    f0 = ops.clip_vit_forward(W, u8, fold_layernorm=False)
+    f3 = ops.clip_vit_forward(W, u8)                      # still cached, still the same
+    assert torch.equal(f1, f3) and (f0 - f1).abs().max().item() < 0.02 * f1.abs().max().item()
+    W.invalidate_fold_cache()
+    assert torch.equal(ops.clip_vit_forward(W, u8), f1)
+    f65 = ops.clip_vit_forward(W, G_(synth.uniform_u8((65, 3, 224, 224), 78)))     # other batch size: new key (and a larger workspace)
+    assert W._fold_key != key and torch.equal(f65[:64], f1)
+    # a workspace full of NaN bytes with the flag forced would NOT be bitwise f1: the flag is really honoured
+    W.workspace(65).fill_(255)
+    W._fold_key = ops._fold_key(W, W.workspace(65), 64)
+    assert not torch.equal(ops.clip_vit_forward(W, u8), f1)
+    W.invalidate_fold_cache()
+    assert torch.equal(ops.clip_vit_forward(W, u8), f1)
+
+
 def test_patch_gather_u8_staged_kernel_equals_the_generic_one():
     """CLIP-L/14 on uint8 frames takes the LDS-staged patch gather (coalesced 16-byte loads, round 5) when the frame buffer is
     16-byte aligned and the generic byte-granular kernel otherwise: the same pixels at a misaligned address must give bitwise the
@@ -745,7 +775,7 @@ def test_residual_statistics_epilogue_against_the_stored_rows(n_frames):
     workspace against the same statistics of the bf16 rows it stored.  64 frames = 64.25 row tiles, 70 frames = 70.27: the ragged
     tile runs through the 64x64 remainder sub-tiles (a second copy of the epilogue; round 5 found a VALU -> asm-MFMA hazard there
     that only this comparison shows: the features of the class-token rows stayed finite).  Workspace layout: clip_carve() of
-    csrc/clip_vit.hip (x | h | qkv | a | u | patches | pooled | stats | spart, 256-byte aligned)."""
+    csrc/clip_vit.hip (the folded weights of all layers | x | h | qkv | a | u | patches | pooled | stats | spart, 256-byte aligned)."""
     cfg = dict(synth.CLIP_L14)
     cfg["layers"] = 1
     state = synth.clip_vision_state(**cfg)
@@ -762,6 +792,8 @@ def test_residual_statistics_epilogue_against_the_stored_rows(n_frames):
         o = (off[0] + 255) // 256 * 256
         off[0] = o + nbytes
         return o
+    Lf = cfg["layers"]
+    take(Lf * 3 * C * C * 2); take(Lf * mlp * C * 2); take(Lf * 3 * C * 4); take(Lf * 3 * C * 4); take(Lf * mlp * 4); take(Lf * mlp * 4)
     ox = take(M * C * 2); take(M * C * 2); take(M * 3 * C * 2); take(M * C * 2); take(M * mlp * 2)
     take(n_frames * 256 * 640 * 2); take(n_frames * C * 2); take(M * 2 * 4)
     osp = take(M * (C // 64) * 2 * 4)

@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libtspo_hip.so")
 
 TSPO_F32, TSPO_BF16, TSPO_F16, TSPO_U8 = 0, 1, 2, 3
-TSPO_CLIP_NO_LN_FOLD, TSPO_CLIP_PRUNE_LAST = 1, 2
+TSPO_CLIP_NO_LN_FOLD, TSPO_CLIP_PRUNE_LAST, TSPO_CLIP_FOLD_CACHED = 1, 2, 4
 ABI_VERSION = 4
 
 _p = C.c_void_p

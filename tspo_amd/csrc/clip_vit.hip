@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void clip_attn257_kernel(const bf16_t* __re
 // ===========================================================================
 struct ClipWs {
   bf16_t *x, *h, *qkv, *a, *u, *patches, *pooled;
-  // LayerNorm-folded path: row statistics, their per-slice partials, and the current layer's folded weights
+  // LayerNorm-folded path: row statistics, their per-slice partials, and every layer's folded weights (layer l at l * size)
   float *stats, *spart, *cq, *dq, *c1, *d1;
   bf16_t *wqkv_f, *w1_f;
   size_t bytes;
@@ -722,6 +722,15 @@ ClipWs clip_carve(void* ws, const tspo_clip_config& c, int n) {
   const int gw = c.image / c.patch, P = gw * gw, S = P + 1;
   const size_t M = (size_t)n * S;
   const int Kp = (int)tspo::align_up((size_t)3 * c.patch * c.patch, 64);
+  // the LayerNorm-folded weights of EVERY layer, at the front (offsets independent of the batch size): a caller whose weights do
+  // not change between calls says so (TSPO_CLIP_FOLD_CACHED) and the 2 x layers fold launches are skipped (round 5)
+  const size_t Lf = (size_t)(c.layers > 0 ? c.layers : 1);
+  w.wqkv_f = cv.take<bf16_t>(Lf * 3 * c.hidden * c.hidden);
+  w.w1_f = cv.take<bf16_t>(Lf * c.mlp * c.hidden);
+  w.cq = cv.take<float>(Lf * 3 * c.hidden);
+  w.dq = cv.take<float>(Lf * 3 * c.hidden);
+  w.c1 = cv.take<float>(Lf * c.mlp);
+  w.d1 = cv.take<float>(Lf * c.mlp);
   w.x = cv.take<bf16_t>(M * c.hidden);
   w.h = cv.take<bf16_t>(M * c.hidden);
   w.qkv = cv.take<bf16_t>(M * 3 * c.hidden);
@@ -731,12 +740,6 @@ ClipWs clip_carve(void* ws, const tspo_clip_config& c, int n) {
   w.pooled = cv.take<bf16_t>((size_t)n * c.hidden);
   w.stats = cv.take<float>(M * 2);
   w.spart = cv.take<float>(M * (size_t)(c.hidden / 64) * 2);
-  w.cq = cv.take<float>((size_t)3 * c.hidden);
-  w.dq = cv.take<float>((size_t)3 * c.hidden);
-  w.c1 = cv.take<float>((size_t)c.mlp);
-  w.d1 = cv.take<float>((size_t)c.mlp);
-  w.wqkv_f = cv.take<bf16_t>((size_t)3 * c.hidden * c.hidden);
-  w.w1_f = cv.take<bf16_t>((size_t)c.mlp * c.hidden);
   w.bytes = cv.bytes();
   return w;
 }
@@ -1051,7 +1054,9 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
   TSPO_REQUIRE(n_frames >= 1, "clip_vit_forward: n_frames=%d", n_frames);
   const tspo_clip_config& c = w->cfg;
   if (int e = clip_check_cfg(c)) return e;
-  TSPO_REQUIRE((flags & ~(TSPO_CLIP_NO_LN_FOLD | TSPO_CLIP_PRUNE_LAST)) == 0, "clip_vit_forward: unknown flags 0x%x", flags);
+  TSPO_REQUIRE((flags & ~(TSPO_CLIP_NO_LN_FOLD | TSPO_CLIP_PRUNE_LAST | TSPO_CLIP_FOLD_CACHED)) == 0,
+               "clip_vit_forward: unknown flags 0x%x", flags);
+  const bool fold_cached = (flags & TSPO_CLIP_FOLD_CACHED) != 0;   // the caller vouches for the folded weights in this workspace
   const bool no_fold = (flags & TSPO_CLIP_NO_LN_FOLD) != 0;   // keep the stand-alone LayerNorm passes
   const bool prune = (flags & TSPO_CLIP_PRUNE_LAST) != 0;     // opt-in: last block evaluated for the class-token row only
   TSPO_REQUIRE(w->patch_w && w->pos_emb && w->pre_g && w->pre_b && w->post_g && w->post_b && w->proj_w &&
@@ -1116,14 +1121,20 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
     TSPO_REQUIRE(L.ln1_g && L.ln1_b && L.wqkv && L.bqkv && L.wo && L.bo && L.ln2_g && L.ln2_b && L.w1 && L.b1 && L.w2 && L.b2,
                  "clip_vit_forward: null pointer in layer %d", l);
     GemmArgs g{};
+    // this layer's folded weights / column sums / folded biases
+    bf16_t* wqkv_f = b.wqkv_f + (size_t)l * 3 * C * C;
+    bf16_t* w1_f = b.w1_f + (size_t)l * c.mlp * C;
+    float *cq = b.cq + (size_t)l * 3 * C, *dq = b.dq + (size_t)l * 3 * C, *c1 = b.c1 + (size_t)l * c.mlp, *d1 = b.d1 + (size_t)l * c.mlp;
     if (fold) {
-      hipLaunchKernelGGL(ln_fold_kernel, dim3((3 * C + 3) / 4), dim3(256), 0, st, (const bf16_t*)L.wqkv, L.bqkv, L.ln1_g, L.ln1_b,
-                         3 * C, C, b.wqkv_f, b.cq, b.dq);
-      hipLaunchKernelGGL(ln_fold_kernel, dim3((c.mlp + 3) / 4), dim3(256), 0, st, (const bf16_t*)L.w1, L.b1, L.ln2_g, L.ln2_b,
-                         c.mlp, C, b.w1_f, b.c1, b.d1);
-      if (int e = tspo::check_launch("ln_fold")) return e;
-      prof.tick(PK_LN);
-      g.A = b.x; g.W = b.wqkv_f; g.bias = b.dq; g.lnc = b.cq; g.rstats = b.stats; g.C = b.qkv;
+      if (!fold_cached) {
+        hipLaunchKernelGGL(ln_fold_kernel, dim3((3 * C + 3) / 4), dim3(256), 0, st, (const bf16_t*)L.wqkv, L.bqkv, L.ln1_g, L.ln1_b,
+                           3 * C, C, wqkv_f, cq, dq);
+        hipLaunchKernelGGL(ln_fold_kernel, dim3((c.mlp + 3) / 4), dim3(256), 0, st, (const bf16_t*)L.w1, L.b1, L.ln2_g, L.ln2_b,
+                           c.mlp, C, w1_f, c1, d1);
+        if (int e = tspo::check_launch("ln_fold")) return e;
+        prof.tick(PK_LN);
+      }
+      g.A = b.x; g.W = wqkv_f; g.bias = dq; g.lnc = cq; g.rstats = b.stats; g.C = b.qkv;
       g.M = (int)M; g.N = 3 * C; g.K = C; g.P = 1;
       if (int e = tspo::gemm_bf16(hm ? GE_BIAS_LN_HM : GE_BIAS_LN, g, st)) return e;
     } else {
@@ -1176,7 +1187,7 @@ static int clip_forward_impl(const tspo_clip_weights* w, const void* pixels, int
       launch_stats_finalize(b.spart, M, C, c.ln_eps, b.stats, st);
       if (int e = tspo::check_launch("stats_finalize")) return e;
       prof.tick(PK_LN);
-      g.A = b.x; g.W = b.w1_f; g.bias = b.d1; g.lnc = b.c1; g.rstats = b.stats; g.C = b.u;
+      g.A = b.x; g.W = w1_f; g.bias = d1; g.lnc = c1; g.rstats = b.stats; g.C = b.u;
       g.M = (int)M; g.N = c.mlp; g.K = C; g.P = 1;
       if (int e = tspo::gemm_bf16(GE_GELU_LN, g, st)) return e;
     } else {

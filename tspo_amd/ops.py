@@ -395,6 +395,12 @@ class ClipVitWeights:
         self.struct = w
         self.device = dev
         self._ws = None
+        self._fold_key = None   # (workspace, batch size, stream) the folded weights kept in the workspace are valid for
+
+    def invalidate_fold_cache(self) -> None:
+        """Forget the LayerNorm-folded weights kept in the workspace (only needed by code that edits the packed weight tensors
+        in place - nothing in this package does)."""
+        self._fold_key = None
 
     def workspace(self, n_frames: int) -> torch.Tensor:
         n = _lib.lib().tspo_clip_workspace_bytes(C.byref(self.struct.cfg), n_frames)
@@ -402,11 +408,20 @@ class ClipVitWeights:
             raise ValueError("clip: bad config")
         if self._ws is None or self._ws.numel() < n:
             self._ws = torch.empty((n,), dtype=torch.uint8, device=self.device)
+            self._fold_key = None
         return self._ws
 
 
-def _clip_flags(fold_layernorm: bool, prune_last_layer: bool) -> int:
-    return (0 if fold_layernorm else _lib.TSPO_CLIP_NO_LN_FOLD) | (_lib.TSPO_CLIP_PRUNE_LAST if prune_last_layer else 0)
+def _clip_flags(fold_layernorm: bool, prune_last_layer: bool, fold_cached: bool = False) -> int:
+    return ((0 if fold_layernorm else _lib.TSPO_CLIP_NO_LN_FOLD) | (_lib.TSPO_CLIP_PRUNE_LAST if prune_last_layer else 0) |
+            (_lib.TSPO_CLIP_FOLD_CACHED if fold_cached and fold_layernorm else 0))
+
+
+def _fold_key(w, ws: torch.Tensor, n_frames: int):
+    """What the folded weights kept in a ClipVitWeights workspace are valid FOR: this buffer, this batch size (which decides
+    whether the library folds at all) and the stream they were written on.  The weights of a ClipVitWeights never change (a new
+    state dict makes a new object, and with it a new workspace)."""
+    return (ws.data_ptr(), ws.numel(), int(n_frames), torch.cuda.current_stream(ws.device).cuda_stream)
 
 
 def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torch.Tensor] = None,
@@ -426,9 +441,15 @@ def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torc
         raise ValueError(f"pixels must be [N,3,{cfg['image']},{cfg['image']}], got {tuple(px.shape)}")
     ws = w.workspace(N)
     feat = out if out is not None else torch.empty((N, cfg["proj"]), dtype=torch.float32, device=px.device)
+    # the LayerNorm-folded weights of all layers stay in the workspace between calls (TSPO_CLIP_FOLD_CACHED): the second and later
+    # encodes of a frozen CLIP tower on the same workspace skip the 2 x layers fold launches
+    key = _fold_key(w, ws, N)
+    cached = fold_layernorm and w._fold_key == key
     check(_lib.lib().tspo_clip_vit_forward_ex(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
-                                              ws.numel(), _stream(), _clip_flags(fold_layernorm, prune_last_layer)),
+                                              ws.numel(), _stream(), _clip_flags(fold_layernorm, prune_last_layer, cached)),
           "tspo_clip_vit_forward")
+    if fold_layernorm:
+        w._fold_key = key
     return feat
 
 
@@ -440,9 +461,13 @@ def clip_vit_profile(w: ClipVitWeights, pixels: torch.Tensor, fold_layernorm: bo
     ws = w.workspace(N)
     feat = torch.empty((N, w.cfg["proj"]), dtype=torch.float32, device=px.device)
     ms = (C.c_float * 6)()
+    key = _fold_key(w, ws, N)
+    cached = fold_layernorm and w._fold_key == key
     check(_lib.lib().tspo_clip_vit_profile(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
-                                           ws.numel(), _stream(), ms, _clip_flags(fold_layernorm, False)),
+                                           ws.numel(), _stream(), ms, _clip_flags(fold_layernorm, False, cached)),
           "tspo_clip_vit_profile")
+    if fold_layernorm:
+        w._fold_key = key
     return {"gemm_ms": ms[0], "attn_ms": ms[1], "ln_ms": ms[2], "gather_ms": ms[3], "total_ms": ms[4],
             "gemm_launches": int(ms[5])}
 
