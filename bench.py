@@ -676,7 +676,7 @@ def main():
         # --pmc passes (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction) of THIS command
         # (tools/prof_round.sh -> tools/pmc_traffic.py); the file name says which round's kernels they were taken on.
         traffic, tsrc = None, None
-        tname = "r5_i_gemm_hbm_traffic_T1024.json" if not a.no_ln_fold else "r1_gemm_hbm_traffic_T1024.json"
+        tname = "r5_j_gemm_hbm_traffic_T1024.json" if not a.no_ln_fold else "r1_gemm_hbm_traffic_T1024.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and B * T == 1024:
             try:
