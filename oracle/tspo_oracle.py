@@ -347,6 +347,29 @@ def tspo_step_autograd(params: Dict[str, torch.Tensor], image, text, clip, noise
     return torch.stack([i[1] for i in idxs]), loss.detach(), grads
 
 
+def tspo_step_autograd_one_forward(params: Dict[str, torch.Tensor], image, text, clip, noise, rewards,
+                                   k: int, window_size: int, tau: float, num_heads: int = 8):
+    """tspo_step_autograd with the G re-evaluations collapsed into ONE differentiable forward.
+
+    The reference re-runs the selector once per rollout (tspo_trainer.py:540-552) on unchanged weights and inputs, so the
+    G confidence vectors are the same tensor G times and the loss (:594-607) is a sum of G gathers from it; autograd's
+    gradient of that sum is the same whether the G copies are separate graphs or one.  This form exists for LONG videos
+    (T = 4096: a dense T x T graph is ~2 GB, G = 16 of them do not fit a test box) and is checked against
+    tspo_step_autograd itself in tests/test_oracle_golden.py.  Returns (idx [G,k], loss, {name: grad}, adv [G], scores [T]).
+    """
+    G = noise.shape[0]
+    ps = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    conf, _ = selector_forward(ps, image, text, clip, window_size, tau, num_heads)
+    with torch.no_grad():
+        idxs = [gumbel_topk(conf.detach(), noise[g], k)[0] for g in range(G)]
+    logp = F.softmax(conf, dim=0).log()                       # model/utils.py:78
+    adv = grpo_advantage(rewards, G)
+    loss = pg_loss([logp[i] for i in idxs], adv)
+    loss.backward()
+    grads = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in ps.items()}
+    return torch.stack(idxs), loss.detach(), grads, adv, conf.detach()
+
+
 # --------------------------------------------------------------------------
 # K16  AdamW (torch.optim.AdamW semantics, HF Trainer default)
 # --------------------------------------------------------------------------

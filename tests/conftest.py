@@ -29,4 +29,4 @@ def pytest_collection_modifyitems(config, items):
 def golden():
     import numpy as np
     gdir = os.path.join(ROOT, "tests", "golden")
-    return {g: np.load(os.path.join(gdir, g + ".npz")) for g in ("selector", "misc", "gumbel", "train", "clip")}
+    return {g: np.load(os.path.join(gdir, g + ".npz")) for g in ("selector", "misc", "gumbel", "train", "train_full", "clip")}

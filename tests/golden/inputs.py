@@ -23,6 +23,10 @@ GUMBEL_CASES = [("g64", 64, 6, 4, 3.0), ("g1024", 1024, 32, 8, 8.0), ("g512", 51
 # (name, T, D, H, window, tau, k, G)
 TRAIN_CASES = [("t48", 48, 64, 8, 12, 0.025, 6, 4), ("t512", 512, 768, 8, 12, 0.02, 16, 8)]
 
+# the policy step at the sizes bench.py TIMES (round 6; BASELINE configs[2] and the policy side of configs[4]):
+# (name, B prompts, T, D, H, window, tau, k, G)
+TRAIN_FULL_CASES = [("c2", 4, 512, 768, 8, 12, 0.025, 16, 8), ("c4", 1, 4096, 768, 8, 12, 0.025, 16, 16)]
+
 CLIP_MID = dict(hidden=128, layers=3, heads=2, mlp=256, patch=14, image=224, proj=64)   # 257 tokens, head_dim 64
 CLIP_CASES = [("clip_tiny", synth.CLIP_TINY, 3), ("clip_mid", CLIP_MID, 2), ("clip_l14", synth.CLIP_L14, 2)]
 
@@ -47,6 +51,20 @@ def train_inputs(name, T, D, G):
         state = synth.selector_state(D, seed=41, std=0.02, bias_std=0.0)   # HF init: N(0,.02), zero bias
     rewards = ((synth.uniform((G,), 77 + T) > 0.5).astype(np.float32) + synth.uniform((G,), 78 + T).astype(np.float32))
     return img, txt, clip, state, rewards
+
+
+def train_full_inputs(name, B, T, D, G):
+    """B prompts of T N(0,1) frame features + one N(0,1) text row each (bench.py's recipe for `rollouts_per_s`), the cosine clip
+    score, HF-init-like selector weights (N(0, 0.02); tspo_trainer.py:201) and per-rollout rewards = accuracy (0/1) +
+    temporal term in [0,1) (tspo_trainer.py:554-573)."""
+    seed = sum(ord(c) for c in name) * 131 + T
+    img = synth.normal((B, T, D), seed + 1)
+    txt = synth.normal((B, 1, D), seed + 2)
+    cs = torch.nn.CosineSimilarity(dim=-1)
+    clip = np.stack([cs(torch.from_numpy(txt[b]), torch.from_numpy(img[b])).numpy() for b in range(B)]).astype(np.float32)
+    state = synth.selector_state(D, seed=43, std=0.02, bias_std=0.01)   # (non-zero biases so the bias paths carry signal)
+    rewards = ((synth.uniform((B, G), seed + 3) > 0.5).astype(np.float32) + synth.uniform((B, G), seed + 4).astype(np.float32))
+    return img, txt, clip, state, rewards.reshape(B, G)
 
 
 def clip_pixels(cfg, n_frames):

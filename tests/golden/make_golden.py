@@ -37,8 +37,8 @@ from model.temporal_agent import MultiModal_Align, TSPOModel, positional_encodin
 from model.utils import gumbel_softmax, generate_uniform_integers, AKS_sampling     # reference
 from tspo_amd import synth
 sys.path.insert(0, HERE)
-from inputs import (SELECTOR_CASES, GUMBEL_CASES, TRAIN_CASES, CLIP_CASES, selector_inputs, gumbel_logits,
-                    train_inputs, clip_pixels)
+from inputs import (SELECTOR_CASES, GUMBEL_CASES, TRAIN_CASES, TRAIN_FULL_CASES, CLIP_CASES, selector_inputs, gumbel_logits,
+                    train_inputs, train_full_inputs, clip_pixels)
 
 torch.manual_seed(0)
 torch.set_num_threads(8)
@@ -196,6 +196,87 @@ def gen_train(out):
         out[f"adv.{nm}.r"] = rt.numpy()
         out[f"adv.{nm}.a"] = ((rt - mean_g) / (std_g + 1e-4)).numpy()
         out[f"adv.{nm}.G"] = np.array(G)
+
+
+def trainer_step_streamed(m, img, txt, clip, w, tau, k, G, rewards, seed0):
+    """trainer_step for LONG videos (T = 4096: the reference's dense T x T attention keeps ~2.5 GB of autograd state per
+    re-evaluation, and tspo_trainer.py:540-552 holds all G of them): the same reference modules and the same literal expressions,
+    but rollout g's term -(exp(lp - sg(lp)).mean() * A_g) / G is back-propagated as soon as it is formed - the gradient is the
+    same sum (fp32 addition order of G terms aside), the memory one graph."""
+    T = img.shape[0]
+    all_ts, noise = [], np.zeros((G, T), np.float32)
+    with torch.no_grad():
+        conf, _ = m(img, txt, clip, w, tau)
+        for g in range(G):
+            noise[g] = draw_gumbel(T, seed0 + g)[:, 0].numpy()
+            torch.manual_seed(seed0 + g)
+            idx, _, _ = gumbel_softmax(conf.unsqueeze(1), sample_len=k)
+            all_ts.append((idx.clone(), idx))
+    mean_g = rewards.view(-1, G).mean(dim=1).repeat_interleave(G, dim=0)
+    std_g = rewards.view(-1, G).std(dim=1).repeat_interleave(G, dim=0)
+    advantages = (rewards - mean_g) / (std_g + 1e-4)
+    m.zero_grad()
+    loss = 0.0
+    for g in range(G):
+        conf, _ = m(img, txt, clip, w, tau)
+        _, _, logp_ts = gumbel_softmax(conf.unsqueeze(1), sample_len=k)
+        sel = logp_ts[all_ts[g][1]]
+        term = -(torch.exp(sel - sel.detach()).mean() * advantages[g]) / G
+        term.backward()
+        loss = loss + term.item()
+        print(f"    rollout {g + 1}/{G} re-evaluated", flush=True)
+    return all_ts, noise, advantages, torch.tensor(loss), conf.detach()
+
+
+def gen_train_full(out):
+    """The policy step at the sizes bench.py times (BASELINE configs[2]: B=4, T=512, G=8, k=16; the policy side of configs[4]:
+    B=1, T=4096, G=16, k=16), through the reference's own modules: every prompt is one tspo_trainer.py:500-609 step, the
+    bucket is the MEAN of the prompts' gradients (what data-parallel averaging / PolicyTrainer's 1/B scale produce), then
+    clip_grad_norm_(1.0) + one AdamW step.  Stored: the noise drawn, indices, advantages, per-prompt losses, the scores, and
+    for every parameter gradient 256 leading + 256 strided elements, three checksums, the small tensors whole; the clip norm
+    and 256 elements of every parameter after the update."""
+    import time
+    for name, B, T, D, H, w, tau, k, G in TRAIN_FULL_CASES:
+        t0 = time.time()
+        img, txt, clip, state, rew = train_full_inputs(name, B, T, D, G)
+        m = ref_selector(D, H, state)
+        acc = {pn: torch.zeros_like(p) for pn, p in m.named_parameters()}
+        noises, idxs, advs, losses, scores = [], [], [], [], []
+        for b in range(B):
+            step = trainer_step if T <= 1024 else trainer_step_streamed
+            all_ts, noise, adv, loss, conf = step(m, torch.from_numpy(img[b]), torch.from_numpy(txt[b]), torch.from_numpy(clip[b]),
+                                                  w, tau, k, G, torch.from_numpy(rew[b]), 6000 + 100 * b + T)
+            for pn, p in m.named_parameters():
+                if p.grad is not None:
+                    acc[pn] += p.grad / B
+            noises.append(noise); idxs.append(np.stack([t[1].numpy() for t in all_ts])); advs.append(adv.numpy())
+            losses.append(float(loss)); scores.append(conf.detach().numpy())
+            print(f"  {name}: prompt {b + 1}/{B} done ({time.time() - t0:.0f}s)", flush=True)
+        out[f"{name}.noise"] = np.stack(noises)
+        out[f"{name}.idx"] = np.stack(idxs)
+        out[f"{name}.adv"] = np.stack(advs)
+        out[f"{name}.loss"] = np.array(losses, np.float64)
+        out[f"{name}.scores"] = np.stack(scores)
+        for pn, p in m.named_parameters():
+            p.grad = acc[pn].clone()
+            gf = acc[pn].flatten()
+            if gf.numel() <= 4096:
+                out[f"{name}.grad.{pn}"] = gf.numpy().copy()
+            else:
+                stride = gf.numel() // 256
+                out[f"{name}.gradsl.{pn}"] = gf[:256].numpy().copy()
+                out[f"{name}.gradst.{pn}"] = gf[stride // 2::stride][:256].numpy().copy()
+            out[f"{name}.gradsum.{pn}"] = np.array([gf.double().sum().item(), gf.double().abs().sum().item(),
+                                                     (gf.double() ** 2).sum().item(), gf.abs().max().item()])
+        params = [p for pn, p in m.named_parameters() if "ffn_o" not in pn]
+        tn = torch.nn.utils.clip_grad_norm_(params, 1.0)
+        out[f"{name}.gradnorm"] = np.array(tn.item(), np.float64)
+        opt = torch.optim.AdamW(params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        opt.step()
+        for pn, p in m.named_parameters():
+            if "ffn_o" not in pn:
+                out[f"{name}.after.{pn}"] = p.detach().flatten()[:256].numpy().copy()
+        print(f"  {name}: |g| = {tn.item():.6f}, losses {losses}", flush=True)
 
 
 def gen_clip(out):
@@ -637,7 +718,7 @@ def gen_full1024(out):
 
 
 def main():
-    groups = {"selector": gen_selector, "misc": gen_misc, "gumbel": gen_gumbel, "train": gen_train, "clip": gen_clip,
+    groups = {"selector": gen_selector, "misc": gen_misc, "gumbel": gen_gumbel, "train": gen_train, "train_full": gen_train_full, "clip": gen_clip,
               "glue": gen_glue, "published": gen_published, "noise": gen_noise, "full1024": gen_full1024}
     which = sys.argv[1:] or list(groups)
     for g in which:

@@ -145,6 +145,46 @@ def test_train_step(golden, case):
         np.testing.assert_allclose(p1.flatten()[:256].numpy(), g[f"{name}.after.{pn}"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["c2", "c4"])
+def test_train_step_at_the_timed_sizes(golden, name):
+    """The policy step at the sizes bench.py times (configs[2]: B=4, T=512, G=8, k=16; policy side of configs[4]: B=1, T=4096,
+    G=16) - oracle vs the fixture `make_golden.py train_full` wrote from the reference's own modules: indices, advantages, losses,
+    scores per prompt, the bucket (mean of the prompts' gradients), its norm and the parameters after clip + AdamW."""
+    import _policy_full as P
+    _, B, T, D, H, w, tau, k, G = P.CASES[name]
+    g = golden["train_full"]
+    img, txt, clip, state, rew = P.train_full_inputs(name, B, T, D, G)
+    mean, per = P.oracle_mean_grads(name, g, range(B))
+    for b, (idx, loss, _, adv, scores) in enumerate(per):
+        np.testing.assert_array_equal(idx.numpy(), g[f"{name}.idx"][b])
+        np.testing.assert_allclose(adv.numpy(), g[f"{name}.adv"][b], rtol=1e-6, atol=1e-6)
+        assert abs(loss.item() - float(g[f"{name}.loss"][b])) < 2e-6
+        np.testing.assert_allclose(scores.numpy(), g[f"{name}.scores"][b], rtol=1e-5, atol=2e-4)
+    P.check_against_fixture(name, g, {n: v.numpy() for n, v in mean.items()}, f"oracle {name}", rtol=1e-4, atol_rel=1e-5)
+    flat = torch.cat([mean[n].flatten() for n in P.TRAINED])
+    tn = flat.norm().item()
+    assert abs(tn - float(g[f"{name}.gradnorm"])) < 1e-4 * tn
+    scale = O.clip_grad_scale(tn, 1.0)
+    for pn in P.TRAINED:
+        if pn == "temporal.Self_k.bias":
+            continue      # zero gradient in exact arithmetic: Adam's first step there is lr x the sign of rounding noise
+        p0 = T_(state[pn])
+        p1, _, _ = O.adamw_step(p0, mean[pn], torch.zeros_like(p0), torch.zeros_like(p0), 1, 5e-4, grad_scale=scale)
+        ok = np.abs(mean[pn].flatten()[:256].numpy()) * scale > 2e-6    # (the first Adam step is lr.g / (|g| + 1e-8): sign-like, ill-conditioned only where |g| ~ eps)
+        np.testing.assert_allclose(p1.flatten()[:256].numpy()[ok], g[f"{name}.after.{pn}"][ok], rtol=1e-5, atol=1e-6)
+    if name == "c2":
+        # the one-forward form (used for T = 4096, where G dense graphs do not fit) == the reference-shaped 2.G-forward loop
+        ps = state_t(state)
+        i1, l1, g1, a1, s1 = O.tspo_step_autograd_one_forward(ps, T_(img[0]), T_(txt[0]), T_(clip[0]), T_(g["c2.noise"][0]),
+                                                                T_(rew[0]), k, w, tau, H)
+        i0, l0, g0, a0, s0 = per[0]
+        assert torch.equal(i0, i1) and torch.equal(a0, a1) and abs(l0.item() - l1.item()) < 1e-6
+        for pn in P.TRAINED:
+            if pn == "temporal.Self_k.bias":
+                continue
+            assert (g0[pn] - g1[pn]).abs().max().item() <= 2e-5 * g0[pn].abs().max().item(), pn   # (fp32 order of the G-term sum)
+
+
 @pytest.mark.parametrize("case", CLIP_CASES, ids=[c[0] for c in CLIP_CASES])
 def test_clip_vit(golden, case):
     tag, cfg, n = case
