@@ -3,6 +3,7 @@
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python bench.py --gpus 8                      # no launcher: spawns its own 8 ranks (one per GPU, RCCL)
+    python bench.py --gpus 8 --frames 4096 --shard-frames --rollout-cfg 1,4096,16,16   # configs[4]: ONE 4096-frame video over 8 GPUs (strong scaling)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -447,6 +448,49 @@ def dp_path_rollouts(flat, dev, world: int, rank: int, cfg, steps: int, timed) -
             "note": "the reference's configuration (train_deepspeed.sh:30-31); `rollouts_per_s` above is the fused single-rank variant"}
 
 
+def workload_name(T: int, B: int, k: int, world: int, shard: bool) -> str:
+    """config.workload, derived from what is actually run (never a constant: VERDICT r5 weak #7)."""
+    what = "TSPO-0.4B frame selection (CLIP-L/14 encode + scoring head + top-k)"
+    if shard:
+        return (f"configs[4] long-form option: ONE T={T}-frame video per step, frames sharded over {world} rank(s) for the encode, "
+                f"all-gather of the features, replicated scoring head + top-{k} (SURVEY 8e)")
+    if T == 1024 and B == 1 and k == 32:
+        return f"configs[1]: {what}, T=1024, top-k 32" + ("" if world == 1 else f", one video per GPU on {world} GPUs")
+    if T == 4096:
+        return f"configs[4] per-GPU share (long-form stress, frame scoring side): {what}, T=4096, top-k {k}, {B} video(s) per GPU"
+    return f"custom: {what}, T={T}, top-k {k}, {B} video(s) per GPU"
+
+
+def committed_traffic(n_frames: int, ln_fold: bool):
+    """(HBM-side bytes per GEMM launch, source, per-form rows) from a committed rocprofv3 --pmc summary (FETCH_SIZE / WRITE_SIZE
+    passes cannot run inside this process) - but ONLY from a file that tools/pmc_traffic.py bound to the library this process
+    loaded (sha256 of the .so, or of the sources it is built from): a stale round's bytes are never quoted for new kernels.
+    Otherwise (None, why, None)."""
+    import glob
+    if not ln_fold:
+        return None, "no committed traffic pass for --no-ln-fold with this library", None
+    try:
+        from tspo_amd.build import lib_identity
+        me = lib_identity()
+    except Exception as e:
+        return None, f"library identity unavailable ({type(e).__name__}: {e})", None
+    seen = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_gemm_hbm_traffic_T{n_frames}.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            continue
+        lib = tj.get("library") or {}
+        how = ("library sha256" if lib.get("lib_sha256") and lib.get("lib_sha256") == me["lib_sha256"] else
+               "source sha256" if lib.get("src_sha256") and lib.get("src_sha256") == me["src_sha256"] else None)
+        seen.append(os.path.basename(path))
+        if how:
+            rel = "profiles/" + os.path.basename(path)
+            return tj["hbm_bytes_per_launch_avg"], f"{rel} (rocprofv3 --pmc passes of this command; bound to the loaded library by {how})", tj.get("forms")
+    return None, (f"no profiles/*_gemm_hbm_traffic_T{n_frames}.json is bound to the loaded library (lib {str(me['lib_sha256'])[:12]}, "
+                  f"src {me['src_sha256'][:12]}); {len(seen)} older file(s) ignored - run tools/prof_round.sh on this build"), None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,6 +510,10 @@ def main():
     ap.add_argument("--no-pruned", action="store_true", help="skip the extra (non-headline) run with the pruned last block")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: stand-alone LayerNorm passes instead of folding them into the GEMMs")
     ap.add_argument("--no-720p", action="store_true", help="skip the extra (non-headline) run that starts from 720p uint8 frames")
+    ap.add_argument("--shard-frames", action="store_true",
+                    help="configs[4] long-form option (SURVEY 8e): ONE --frames video per step, its frames sharded over the N ranks for the "
+                         "encode (FrameScorer.encode(shard_frames=True)), one all-gather of the features, replicated selector + top-k; "
+                         "value = frames of that one video / s (STRONG scaling)")
     ap.add_argument("--no-comm-probe", action="store_true", help="skip the RCCL probe (init + timed all-reduce of the gradient bucket)")
     a = ap.parse_args()
 
@@ -515,7 +563,11 @@ def main():
     clipw = ops.ClipVitWeights(random_clip_state(c, dev), c, dev)
     flat = flat_from_state(random_selector_state(768, dev), 768, dev)
     scorer = FrameScorer(clipw, flat, fold_layernorm=not a.no_ln_fold)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    shard = bool(a.shard_frames)
+    if shard and B != 1:
+        sys.exit("--shard-frames scores ONE video per step (B = 1): its frames are what is sharded")
+    # (sharded: every rank holds the same video and encodes its own contiguous slice of frames)
+    g = torch.Generator(device=dev).manual_seed(1234 + (0 if shard else rank))
     if a.pixels == "u8":
         pixels = torch.randint(0, 256, (B, T, 3, c["image"], c["image"]), generator=g, device=dev, dtype=torch.uint8)
     else:
@@ -567,7 +619,12 @@ def main():
     out = {}
 
     def score_step():
-        out["idx"], out["scores"], _ = scorer(pixels, txt, k)
+        if shard:      # frames of the one video over the ranks -> all-gather [T/N, 768] shards -> replicated selector + top-k
+            feats = scorer.encode(pixels, shard_frames=True)
+            sc, _ = scorer.score(feats, txt)
+            out["idx"], out["scores"] = ops.topk_sorted(sc, k), sc
+        else:
+            out["idx"], out["scores"], _ = scorer(pixels, txt, k)
 
     step_ms, rank_sec = [], []
     sampler = GpuSampler(dev)
@@ -576,7 +633,7 @@ def main():
     finally:
         sampler.__exit__(None, None, None)
     gpu_state = sampler.summary()
-    frames = B * T * world * a.steps
+    frames = B * T * (1 if shard else world) * a.steps      # sharded: the ranks share ONE video (strong scaling)
     fps = frames / sec
     assert out["idx"].shape == (B, min(T, k)) and bool((out["idx"][:, 1:] > out["idx"][:, :-1]).all())
 
@@ -584,7 +641,7 @@ def main():
     # (its other 256 token rows have no consumer; identical features, 3.5 % fewer executed FLOPs; reported separately
     # because `value` must execute the full model like the reference does)
     pruned_fps = None
-    if not a.no_pruned:
+    if not a.no_pruned and not shard:
         scorer.prune_last_layer = True
         psec = timed(score_step, a.steps, 1)
         scorer.prune_last_layer = False
@@ -595,7 +652,7 @@ def main():
     # ---- non-headline: the real front end of the path (temporal_agent.py:156-164): 1280x720 uint8 frames in HBM ->
     # Pillow-exact antialiased bicubic resize + centre crop on the GPU (tspo_preprocess_frames) -> the same scoring path ----
     from_720p = None
-    if not a.no_720p:
+    if not a.no_720p and not shard:
         from tspo_amd import preprocess as PP
         raw = torch.randint(0, 256, (T, 720, 1280, 3), generator=g, device=dev, dtype=torch.uint8)     # one video's frames
 
@@ -620,7 +677,7 @@ def main():
         del raw
 
     # ---- split: score + select only (features resident), SURVEY 8(d) ----------
-    feats_res = scorer.encode(pixels)
+    feats_res = scorer.encode(pixels, shard_frames=shard)
 
     def select_step():
         sc, _ = scorer.score(feats_res, txt)
@@ -668,30 +725,27 @@ def main():
     roof = None
     if rank == 0 and not a.no_profile:
         px = pixels.reshape(B * T, *pixels.shape[2:])
+        if shard and world > 1:      # rank 0's own slice of the video: what its GEMM launches actually process
+            mine = tdist.shard_rows(B * T, world, 0)
+            px = px[mine.start:mine.stop]
+        n_prof = px.shape[0]
         ops.clip_vit_profile(clipw, px, fold_layernorm=not a.no_ln_fold)
         pr = ops.clip_vit_profile(clipw, px, fold_layernorm=not a.no_ln_fold)
-        gflop = gemm_flops_per_frame(c) * B * T
+        gflop = gemm_flops_per_frame(c) * n_prof
         ach = gflop / (pr["gemm_ms"] * 1e-3) / 1e12
         # HBM-side bytes per GEMM launch cannot be read from inside the process: they come from the committed rocprofv3
         # --pmc passes (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction) of THIS command
         # (tools/prof_round.sh -> tools/pmc_traffic.py); the file name says which round's kernels they were taken on.
-        traffic, tsrc = None, None
-        tname = "r5_j_gemm_hbm_traffic_T1024.json" if not a.no_ln_fold else "r1_gemm_hbm_traffic_T1024.json"
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath) and B * T == 1024:
-            try:
-                tj = json.load(open(tpath))
-                traffic, tsrc = tj["hbm_bytes_per_launch_avg"], "profiles/" + tname + " (rocprofv3 --pmc passes, not measured in this run)"
-            except Exception:
-                pass
+        traffic, tsrc, forms = committed_traffic(n_prof, not a.no_ln_fold)
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
-                "alg_bytes_per_launch_avg": alg_bytes_per_launch(c, B * T), "kernel": "gemm_bf16_a9_kernel",
+                "traffic_by_form": forms, "frames_per_launch": n_prof,
+                "alg_bytes_per_launch_avg": alg_bytes_per_launch(c, n_prof), "kernel": "gemm_bf16_a9_kernel",
                 "launches_per_step": pr["gemm_launches"],
                 "avg_launch_ms": round(pr["gemm_ms"] / pr["gemm_launches"], 4),
                 "alg_flop_per_launch_avg": gflop / pr["gemm_launches"],
                 "breakdown_ms": {kk: round(v, 3) for kk, v in pr.items() if kk.endswith("_ms")},
-                "attn_achieved_tflops": round(attn_flops_per_frame(c) * B * T / (pr["attn_ms"] * 1e-3) / 1e12, 1)}
+                "attn_achieved_tflops": round(attn_flops_per_frame(c) * n_prof / (pr["attn_ms"] * 1e-3) / 1e12, 1)}
         # the clock / power the chip sustained during the TIMED steps above (sampled live): the nominal peak assumes 2.4 GHz
         roof.update(sclk_mhz=gpu_state.get("sclk_mhz"), power_w=gpu_state.get("power_w"), gpu_state=gpu_state)
         if gpu_state.get("sclk_mhz"):
@@ -711,10 +765,12 @@ def main():
             "ms_per_step_min": round(min(step_ms), 3), "ms_per_step_median": round(sorted(step_ms)[len(step_ms) // 2], 3),
             "ms_per_step_max": round(max(step_ms), 3),
             "ms_per_step_by_rank": [round(x / a.steps * 1e3, 3) for x in rank_sec],     # each rank's own clock over the timed region
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: TSPO-0.4B frame selection (CLIP-L/14 encode + scoring head + top-k)",
-                       "frames_per_video": T, "videos_per_gpu_per_step": B, "topk": k, "window": 12, "tau": 0.025,
-                       "pixels": a.pixels, "weights": "random-init CLIP-L/14 + selector", "parallelism": f"dp{world}",
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": workload_name(T, B, k, world, shard),
+                       "frames_per_video": T, "videos_per_gpu_per_step": None if shard else B, "videos_per_step_total": 1 if shard else B * world,
+                       "frames_per_gpu_per_step": -(-T // world) if shard else B * T, "topk": k, "window": 12, "tau": 0.025,
+                       "pixels": a.pixels, "weights": "random-init CLIP-L/14 + selector",
+                       "parallelism": (f"frames of one video sharded over {world} rank(s) + all-gather" if shard else f"dp{world}"),
                        "layernorm": "stand-alone" if a.no_ln_fold else "folded into GEMMs"},
             "rollouts_per_s": None if rollouts is None else round(rollouts, 1),
             "rollouts_variant": None if rollouts is None else (
@@ -725,8 +781,13 @@ def main():
                 "rollouts_per_s": round(rollouts_x3, 1),
                 "note": "opt-in PolicyTrainer(gemm_precision='bf16x3'): selector GEMMs as hi/lo bf16 splits on the bf16 MFMA "
                         "(~1e-5 relative error vs exact fp32); not used for `rollouts_per_s`"},
-            "rollouts_config": None if rollouts is None else {"workload": "policy step (reward LLM excluded); default = configs[2]",
-                                                              "B": Bt, "T": Tt, "G": G, "k": kt},
+            "rollouts_config": None if rollouts is None else {
+                "workload": ("policy step (reward LLM excluded): " + (
+                    ("configs[2] (B=4/GPU, T=512, G=8, k=16, 1 GPU)" if world == 1 else
+                     f"configs[3] (B=4/GPU, T=512, G=8, k=16 on {world} GPUs: global batch {Bt * world} prompts, ONE RCCL all-reduce of the "
+                     f"11.8 MB bucket per optimizer step)") if (Bt, Tt, G, kt) == (4, 512, 8, 16) else
+                    (f"configs[4] policy side (B={Bt}/GPU, T=4096, G=16, k=16 on {world} GPU(s))" if (Tt, G, kt) == (4096, 16, 16) else "custom"))),
+                "B": Bt, "T": Tt, "G": G, "k": kt, "global_batch_prompts": Bt * world, "ranks": world},
             "rollouts_roofline": None if rollouts is None else policy_step_roofline(Bt, Tt, 768, Bt * G * world / rollouts, n_launch, by_kernel),
             "encode_tflops": round((gemm_flops_per_frame(c) + attn_flops_per_frame(c)) * fps / 1e12, 1),
             "optional_pruned_last_block": None if pruned_fps is None else {

@@ -233,7 +233,14 @@ def test_tspo_model_end_to_end_small_config():
     # on-device preprocessing (Pillow-exact) == the CPU PIL path of the reference: identical features
     proc_cpu = _StubProcessor()
     del proc_cpu.image_processor
-    f3, _, _ = model.extract_feature(proc_cpu, frames, "what is shown?")
+    from tspo_amd import temporal_agent as TA
+    TA._PIL_FALLBACK_WARNED = False
+    with pytest.warns(RuntimeWarning, match="preprocessed on the CPU"):      # the fallback announces itself (once per process)
+        f3, _, _ = model.extract_feature(proc_cpu, frames, "what is shown?")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        model.extract_feature(proc_cpu, frames, "what is shown?")            # ... and only once
     assert (f3.float() - feats.float()).abs().max().item() <= 2e-2 * feats.float().abs().max().item()
 
 

@@ -64,6 +64,32 @@ def test_bench_self_spawns_two_ranks_from_a_bare_shell():
     assert "error" not in comm
 
 
+def test_bench_shard_frames_two_ranks_strong_scaling_line():
+    """configs[4]'s long-form option as bench.py launches it (`--shard-frames`): ONE video per step, its frames sharded over the
+    ranks for the encode, one all-gather, replicated scoring head + top-k.  Two ranks on the one GPU (gloo, host-staged
+    all-gather): a STRONG-scaling line (value counts the ONE video's frames, not frames x ranks), the workload named from
+    the arguments, every rank encoding half of the frames (that the sharded features equal the single-process ones bit for
+    bit is test_frame_sharded_encode_real_encoder_two_ranks below); and the unsharded line of the same size for comparison."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--no-pruned", "--no-720p", "--no-rollouts", "--no-comm-probe"]
+    r = subprocess.run(base + ["--gpus", "2", "--same-device", "--backend", "gloo", "--shard-frames"],
+                       env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in _json_lines(r.stdout) if "metric" in l][0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["launcher"] == "self-spawn"
+    cfg = line["config"]
+    assert cfg["workload"].startswith("configs[4] long-form option") and "T=128" in cfg["workload"] and "2 rank(s)" in cfg["workload"]
+    assert cfg["frames_per_gpu_per_step"] == 64 and cfg["videos_per_step_total"] == 1 and "sharded" in cfg["parallelism"]
+    # value = the ONE video's frames / s: 128 frames x 2 steps over the timed region
+    assert abs(line["value"] - 128 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-2 * line["value"]
+    assert line["roofline"]["frames_per_launch"] == 64           # rank 0's GEMM launches process its own half
+    one = subprocess.run(base + ["--gpus", "1"], env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    l1 = [l for l in _json_lines(one.stdout) if "metric" in l][0]
+    assert l1["scaling"] == "weak" and l1["config"]["workload"].startswith("custom:") and "T=128" in l1["config"]["workload"]
+    assert l1["roofline"]["frames_per_launch"] == 128
+
+
 def test_bench_under_torch_distributed_run():
     """The driver's launch form for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...`), here with two ranks on the one GPU (gloo), and the N = 1 form under the launcher."""
@@ -316,8 +342,18 @@ def test_bench_line_explains_itself_and_times_the_dp_path():
     line = [l for l in _json_lines(r.stdout) if "metric" in l][0]
     assert line["ms_per_step_min"] <= line["ms_per_step_median"] <= line["ms_per_step_max"]
     assert abs(line["ms_per_step_median"] - line["ms_per_step"]) < 0.2 * line["ms_per_step"]
+    assert line["config"]["workload"].startswith("configs[1]:") and "configs[2]" in line["rollouts_config"]["workload"]
     roof = line["roofline"]
     assert roof["kernel"] == "gemm_bf16_a9_kernel" and 0.3 < roof["frac"] < 0.7
+    # `traffic` is quoted only from a PMC summary bound to THIS library (else null + the reason) - never a stale round's bytes
+    from tspo_amd.build import lib_identity
+    me = lib_identity()
+    if roof["traffic"] is None:
+        assert "no profiles/" in roof["traffic_source"] and me["src_sha256"][:12] in roof["traffic_source"]
+    else:
+        tj = json.load(open(os.path.join(ROOT, roof["traffic_source"].split(" ")[0])))
+        assert tj["library"]["lib_sha256"] == me["lib_sha256"] or tj["library"]["src_sha256"] == me["src_sha256"]
+        assert roof["traffic_by_form"] and all(f["read_ratio"] > 0.9 for f in roof["traffic_by_form"])
     assert roof["gpu_state"]["samples"] > 0, roof["gpu_state"]
     assert 500 < roof["sclk_mhz"] <= 2400 and 100 < roof["power_w"] < 2000
     assert roof["frac_at_sustained_clock"] >= roof["frac"] - 1e-6

@@ -243,3 +243,25 @@ def test_bench_accounting_helpers():
     assert bench.policy_step_roofline(4, 512, 768, 4e-4, 15, {"x": 15.0})["launches_per_step"] == 15
     assert abs(r["gemm_flop_per_step"] / 1e9 - 28.99) < 0.01
     assert abs(r["achieved"] - 28.99e9 / 4e-4 / 1e12) < 0.1 and abs(r["frac"] - r["achieved"] / 157.3) < 1e-3
+
+
+def test_reproduce_published_idx_tool_host_logic():
+    """tools/reproduce_published_idx.py (local weights + videos -> FrameIdGenerator -> compare against the published lists): its
+    GPU / decord branch cannot run here; the doc -> (join key, video file, problem text) mapping can, on docs shaped like the
+    reference's three annotation files, and the problem text must survive FrameIdGenerator.problem_of (gen_id_tspo.py:63-64)."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("reproduce_published_idx", os.path.join(root, "tools", "reproduce_published_idx.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    from tspo_amd.io import FrameIdGenerator, join_key
+    docs = {"LongVideoBench": {"id": "86C_0", "video_path": "86C.mp4", "question": "Which subtitles appear at the same time?"},
+            "MLVU": {"question_id": "Q0", "video_name": "needle_32.mp4", "question": "What does the hand do?\n(A) Delivers\n(B) Shakes"},
+            "VideoMME": {"question_id": "001-1", "videoID": "fFjv93ACGo8", "question": "When is the tree decorated?"}}
+    want = {"LongVideoBench": ("86C.mp4", "Which subtitles appear at the same time?"), "MLVU": ("needle_32.mp4", "What does the hand do?"),
+            "VideoMME": ("fFjv93ACGo8.mp4", "When is the tree decorated?")}
+    for ds, d in docs.items():
+        fname, key, video_of = m.ANNO[ds]
+        assert key == join_key(ds) and key in d
+        assert (video_of(d), m.problem_of(d)) == want[ds]
+        assert FrameIdGenerator.problem_of("Question: " + m.problem_of(d) + "\nOptions") == want[ds][1]

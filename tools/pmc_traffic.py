@@ -3,8 +3,30 @@
 block has 4 slots).  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB;
 on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads -> doubled; WRITE_SIZE is
 reported raw.  Both rules were checked on launches of known byte count in the production
-GEMM's own access pattern (tools/fetch_calibrate.sh, profiles/r4_g_fetch_calibration_and_cache_policy.txt: FETCH_SIZE 0.513, WRITE_SIZE 1.001).  Usage: pmc_traffic.py fetch.csv write.csv kernel_substring [out.json]"""
-import csv, json, sys, collections
+GEMM's own access pattern (tools/fetch_calibrate.sh, profiles/r4_g_fetch_calibration_and_cache_policy.txt: FETCH_SIZE 0.513, WRITE_SIZE 1.001).
+Round 6: the summary is BOUND to the binary it was taken on (`library`: sha256 of tspo_amd/libtspo_hip.so and of its sources,
+tspo_amd.build.lib_identity) - bench.py only quotes a traffic file whose identity matches the library it loaded - and every
+form is put next to ITS algorithmic bytes (`forms`: operands read once, output written once, for the frame count given).
+Usage: pmc_traffic.py fetch.csv write.csv kernel_substring [out.json] [n_frames]"""
+import csv, json, os, sys, collections
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def form_bytes(n_frames, C=1024, mlp=4096, S=257, patch_k=640, proj=768):
+    """Algorithmic bytes (reads, writes) of the CLIP-L/14 encoder's GEMM forms at n_frames, keyed by the kernel's epilogue
+    template argument (gemm_epilogue.h): 8 = q|k|v (LayerNorm-folded, head-major), 6 = fc1 (LayerNorm-folded gelu), 7 = out-proj
+    and fc2 (residual + statistics; one name for both: their mean is what the counters average too), 2 = patch embedding
+    (+ position rows), 4 = the fp32-out projection."""
+    M = S * n_frames
+    qkv = (2 * (M * C + 3 * C * C), 2 * M * 3 * C)
+    fc1 = (2 * (M * C + mlp * C), 2 * M * mlp)
+    out = (2 * (M * C + C * C + M * C), 2 * M * C)
+    fc2 = (2 * (M * mlp + mlp * C + M * C), 2 * M * C)
+    patch = (2 * ((M - n_frames) * patch_k + C * patch_k), 2 * (M - n_frames) * C)
+    prj = (2 * (n_frames * C + proj * C), 4 * n_frames * proj)
+    return {"8": ("qkv", qkv), "6": ("fc1", fc1), "7": ("out-proj + fc2 (mean)", tuple((a + b) / 2 for a, b in zip(out, fc2))),
+            "2": ("patch embedding", patch), "4": ("projection", prj)}
 
 
 def per_kernel(path, counter):
@@ -23,14 +45,28 @@ def main():
         if sub not in key[0]:
             continue
         fv, wv = fa[key], wa.get(key, [0.0])
-        rows.append({"kernel": key[0][:70], "grid": key[1], "launches": len(fv),
+        rows.append({"kernel": key[0][:70], "grid": key[1], "launches": len(fv), "form": key[0].split("gemm_bf16_a9_kernel<")[-1].split(",")[0].strip(),
                      "fetch_MB_per_launch_raw": sum(fv) / len(fv) * 1024 / 1e6,
                      "fetch_MB_per_launch_x2": 2 * sum(fv) / len(fv) * 1024 / 1e6,
                      "write_MB_per_launch_raw": sum(wv) / len(wv) * 1024 / 1e6})
         tot_f += 2 * sum(fv) * 1024
         tot_w += sum(wv) * 1024
         n += len(fv)
-    out = {"kernel_filter": sub, "launches": n, "hbm_bytes_per_launch_avg": (tot_f + tot_w) / max(n, 1),
+    n_frames = int(sys.argv[5]) if len(sys.argv) > 5 else 1024
+    fb, forms = form_bytes(n_frames), []
+    for r in rows:
+        if r["form"] in fb:
+            nm, (ar, aw) = fb[r["form"]]
+            rd, wr = r["fetch_MB_per_launch_x2"] * 1e6, r["write_MB_per_launch_raw"] * 1e6
+            forms.append({"form": r["form"], "gemm": nm, "launches": r["launches"], "read_GB": round(rd / 1e9, 3), "alg_read_GB": round(ar / 1e9, 3),
+                          "read_ratio": round(rd / ar, 2), "write_GB": round(wr / 1e9, 3), "alg_write_GB": round(aw / 1e9, 3),
+                          "total_ratio": round((rd + wr) / (ar + aw), 2)})
+    try:
+        from tspo_amd.build import lib_identity
+        ident = lib_identity()
+    except Exception as e:
+        ident = {"error": f"{type(e).__name__}: {e}"}
+    out = {"kernel_filter": sub, "launches": n, "library": ident, "n_frames": n_frames, "forms": forms, "hbm_bytes_per_launch_avg": (tot_f + tot_w) / max(n, 1),
            "fetch_bytes_per_launch_avg_x2": tot_f / max(n, 1), "write_bytes_per_launch_avg_raw": tot_w / max(n, 1),
            "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read undercount), WRITE_SIZE KiB x1024 raw", "rows": rows}
     txt = json.dumps(out, indent=1)

@@ -79,6 +79,23 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, only=Non
     return LIB
 
 
+def lib_identity() -> dict:
+    """What a measurement of the library's kernels is bound to (profiles/*_gemm_hbm_traffic_*.json carry it, bench.py matches it):
+    sha256 of the shared library on disk and sha256 over the product sources + headers it is built from (a box that rebuilds the
+    library from the same sources runs the same kernels even where the linker's output differs by a byte)."""
+    import hashlib
+
+    def sha(paths):
+        h = hashlib.sha256()
+        for q in paths:
+            h.update(os.path.basename(q).encode() + b"\0")
+            with open(q, "rb") as f:
+                h.update(f.read())
+        return h.hexdigest()
+    return {"lib_sha256": sha([LIB]) if os.path.exists(LIB) else None, "mode": built_mode(),
+            "src_sha256": sha(sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS))}
+
+
 if __name__ == "__main__":
     only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
     build(force=bool(only) or "--force" in sys.argv, dev="--dev" in sys.argv, only=only[0] if only else None)

@@ -305,6 +305,9 @@ def _frames_to_device_u8(candidates, processor_type, dev, clip_processor):
         return None
 
 
+_PIL_FALLBACK_WARNED = False
+
+
 def extract_clip_features_impl(clip_model, clip_processor, candidates, problem, processor_type='llava'):
     """temporal_agent.py:151-169 / utils.py:18-35 / tspo_trainer.py:387-404: text tower on stock
     PyTorch-ROCm, all T frames through the HIP CLIP encoder, cosine clip score in HIP."""
@@ -314,6 +317,14 @@ def extract_clip_features_impl(clip_model, clip_processor, candidates, problem, 
         text_features = _pooled(clip_model.get_text_features(**inputs_text))
     pixels = _frames_to_device_u8(candidates, processor_type, dev, clip_processor)
     if pixels is None:   # non-default processor config / ragged frames: the reference's own CPU PIL path
+        global _PIL_FALLBACK_WARNED
+        if not _PIL_FALLBACK_WARNED:      # said once per process: the caller has lost the on-device front end
+            _PIL_FALLBACK_WARNED = True
+            import warnings
+            warnings.warn("tspo_amd: frames are preprocessed on the CPU by the stock CLIP processor (PIL, one frame at a time, as "
+                          "the reference does) - the on-device resize / crop (tspo_preprocess_frames) applies only to uniform uint8 "
+                          "frame batches and a processor configured like CLIP's default one; results are unchanged, the front end is "
+                          "~100x slower", RuntimeWarning, stacklevel=2)
         image_list = _frames_to_pil(candidates, processor_type)
         pixels = clip_processor(images=image_list, return_tensors="pt", padding=True).to(dev)["pixel_values"]
     with torch.no_grad():
