@@ -631,9 +631,12 @@ def gen_noise(_out):
                         e2e_texts, e2e_video_seed)
     g = {"clip": {}, "selector": {}, "encode": {}, "e2e": {}}
     only_e2e = os.environ.get("TSPO_NOISE_ONLY_E2E") == "1"     # regenerate the end-to-end group only, keep the rest of the file
+    only_new = os.environ.get("TSPO_NOISE_ONLY_NEW") == "1"      # add the end-to-end scenarios the file does not hold yet, keep everything else
+    only_e2e = only_e2e or only_new
     if only_e2e:
         g = json.load(open(os.path.join(HERE, "bf16_noise.json")))
-        g["e2e"] = {}
+        if not only_new:
+            g["e2e"] = {}
 
     # small models: the golden CLIP cases
     for tag, cfgd, n in ([] if only_e2e else CLIP_CASES[:2]):
@@ -649,6 +652,8 @@ def gen_noise(_out):
     # the whole pipeline (bf16 encode -> bf16 scoring head) on the end-to-end test's videos, planted-scene and independent text
     sel = e2e_selector_state()
     for name, (wname, n, needles) in E2E_SCENARIOS.items():
+        if name in g["e2e"]:
+            continue
         f32, f16 = _both(_clip_model(synth.CLIP_L14, clip_l14_state(wname)), _normalize_u8(e2e_video(n, needles, e2e_video_seed(name))))
         per_text = {tn: _head_noise(f32, f16, tx, sel, E2E_WINDOW, E2E_TAU) for tn, tx in e2e_texts(f32, needles).items()}
         g["e2e"][name] = {"frames": n, "tau": E2E_TAU, "features": _feat_stats(f32, f16), "texts": per_text,

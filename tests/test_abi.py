@@ -194,3 +194,15 @@ def test_attention_kernel_register_audit(tmp_path):
     body = re.findall(r"^(_Z\S*clip_attn257_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end", txt, flags=re.S | re.M)[0][1]
     scratch = [ln.strip().split()[0] for ln in body.split("\n") if ln.strip().startswith("scratch_")]
     assert sorted(scratch) in ([], ["scratch_load_dword", "scratch_store_dword"]), scratch      # one store + one reload per item, or none
+
+
+def test_build_names_the_validated_toolchain():
+    """the wait states around the inline-asm MFMAs were validated with ONE compiler; building with another, or with
+    extra flags, must say so and name the post-build checks (it is not an error)."""
+    from tspo_amd import build as b
+    assert b.toolchain_note(b._hipcc(), []) == "", "this image's hipcc is the validated toolchain"
+    note = b.toolchain_note(b._hipcc(), ["-O2"])
+    assert "TSPO_EXTRA_HIPCC_FLAGS=-O2" in note and "code_audit" in note
+    assert "not the validated" in b.toolchain_note("/bin/echo", [])
+    ident = b.lib_identity()
+    assert ident["mode"] == "product" and len(ident["src_sha256"]) == 64 and len(ident["lib_sha256"]) == 64

@@ -54,7 +54,8 @@ def _flat(sel):
     return flat.to(DEV)
 
 
-HEAVY = ["heavy_tailed", "heavy_tailed_s2", "heavy_tailed_s3"]
+HEAVY = ["heavy_tailed"] + [f"heavy_tailed_s{i}" for i in range(2, 9)]      # eight videos since round 6 (three in round 5)
+_EPS, _EXTREMES = {}, {}      # scenario -> (HIP, reference-bf16) largest score error in logits; scenario -> (max-error ratio, largest-1-cos ratio)
 _RATIOS = {}      # scenario -> (largest HIP score error over the six texts) / (the reference's own bf16 score error on the same video)
 
 
@@ -62,15 +63,29 @@ def test_pixels_to_indices_normal_weights():
     _pixels_to_indices("normal")
 
 
-def test_pixels_to_indices_heavy_tailed_three_videos():
-    """Heavy-tailed weights (outlier channels, LayerNorm gains up to 8, like trained CLIP checkpoints) on three videos: every
-    case within 1.5 x the reference's own bf16 score noise on that video, and the MEDIAN of the three within 1.25 x - one sample
-    of this ratio is a draw from a wide distribution (round 4 sat at x 1.49 on the first video alone)."""
+def test_pixels_to_indices_heavy_tailed_eight_videos():
+    """Heavy-tailed weights (outlier channels, LayerNorm gains up to 8, like trained CLIP checkpoints) on EIGHT videos (three in round
+    5).  The largest score error of ONE 64-frame video over six texts is an extreme statistic: the reference's OWN bf16 path draws
+    0.37 ... 1.05 logits on these videos, the HIP path 0.36 ... 0.89, and their per-video ratio spreads over 0.61 ... 1.49 although the
+    two distributions coincide (means 0.635 vs 0.659 logits, measured on MI355X, profiles/r6_f_e2e_eight_heavy_tailed_videos.txt).
+    So the bounds that bind are over the SAMPLE: every video within 1.5 x the reference's own noise on that video (kept from
+    round 4), the MEDIAN ratio <= 1.15, and the MEAN HIP error <= 1.1 x the MEAN reference error.  Same for the feature extremes
+    (largest error, smallest cosine of 64 frames: per video <= 2 x - measured spread 0.53 ... 1.63 -, median over the videos <= 1.25 x)."""
+    import statistics
     for sc in HEAVY:
         _pixels_to_indices(sc)
     r = sorted(_RATIOS[sc] for sc in HEAVY)
-    print(f"\n[e2e heavy-tailed] HIP / reference-bf16 score-error ratios over the three videos: {[round(x, 3) for x in r]}, median {r[1]:.3f}")
-    assert r[1] <= 1.25, f"median ratio {r[1]}"
+    med = statistics.median(r)
+    hip, ref = [_EPS[sc][0] for sc in HEAVY], [_EPS[sc][1] for sc in HEAVY]
+    print(f"\n[e2e heavy-tailed] HIP / reference-bf16 score-error ratios over the {len(HEAVY)} videos: {[round(x, 3) for x in r]}, median {med:.3f}; "
+          f"mean error HIP {sum(hip) / len(hip):.4f} vs reference-bf16 {sum(ref) / len(ref):.4f} logits (x{sum(hip) / sum(ref):.3f})")
+    assert max(r) <= 1.5 and med <= 1.15, f"per-video ratios {r}"
+    assert sum(hip) <= 1.1 * sum(ref), f"mean score error {sum(hip) / len(hip)} vs the reference's own {sum(ref) / len(ref)}"
+    ex_err = sorted(_EXTREMES[sc][0] for sc in HEAVY)
+    ex_cos = sorted(_EXTREMES[sc][1] for sc in HEAVY)
+    print(f"    feature extremes, HIP / reference-bf16 per video: max error {[round(x, 2) for x in ex_err]} (median {statistics.median(ex_err):.2f}), "
+          f"largest 1-cos {[round(x, 2) for x in ex_cos]} (median {statistics.median(ex_cos):.2f})")
+    assert statistics.median(ex_err) <= 1.25 and statistics.median(ex_cos) <= 1.25
 
 
 def _pixels_to_indices(scenario):
@@ -112,7 +127,8 @@ def _pixels_to_indices(scenario):
     print(f"\n[e2e {scenario}, {n} frames] feature err {ferr:.4f} of range; score err eps = {eps:.4f} logits "
           f"(= {eps * TAU:.5f} in cosine units); oracle score spread {spread:.2f} logits")
     assert ferr < 3e-2
-    # free-standing ceiling in cosine units: 0.02, or - on the videos where the reference's own bf16 path sits above that - its noise
+    # free-standing ceiling in cosine units: 0.02 - NOT raised - except on the videos where the reference's own bf16 path itself sits
+    # above it (heavy_tailed_s3: 0.0263, s4: 0.0232), where the ceiling is 1.1 x that noise
     assert eps * TAU <= max(0.02, 1.1 * noise["max_score_eps_logits"] * TAU), f"end-to-end score error {eps * TAU} cosine units"
     # ---- the binding tolerance: the reference's own bf16-vs-fp32 noise on this video (tests/golden/bf16_noise.json) ----
     cos_all = torch.nn.functional.cosine_similarity(f_hip[0].cpu().double(), f_ref.double(), dim=-1)
@@ -126,6 +142,7 @@ def _pixels_to_indices(scenario):
     # equivalent kernels - round 5, tests/test_gpu_ops.py:_assert_within_reference_noise)
     assert rms <= 1.25 * rf["rms_err_over_range"] and m1c <= 1.25 * rf["mean_one_minus_cos"]
     assert ferr <= 2.0 * rf["err_over_range"] and 1 - cosf <= 2.0 * (1 - rf["min_cos"])
+    _EXTREMES[scenario] = (ferr / rf["err_over_range"], (1 - cosf) / (1 - rf["min_cos"]))
     eps_by_text = {}
     for tn, tq in texts.items():
         with torch.no_grad():
@@ -162,6 +179,7 @@ def _pixels_to_indices(scenario):
     print(f"    largest score error over the {len(texts)} texts: HIP {worst:.4f} logits, reference-bf16 {ref_worst:.4f} (x{worst / ref_worst:.2f})")
     assert worst <= 1.5 * ref_worst, f"score error {worst} logits > 1.5 x the reference's own bf16 noise {ref_worst}"
     _RATIOS[scenario] = worst / ref_worst
+    _EPS[scenario] = (worst, ref_worst)
 
     order = torch.argsort(s_ref, descending=True, stable=True)
     for k in (len(needles), 8, 32):

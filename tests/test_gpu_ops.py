@@ -736,31 +736,47 @@ def test_gemm_remainder_phase_bitwise_at_encoder_size(N, K):
 def test_folded_weights_stay_in_the_workspace_between_calls():
     """Round 5: the LayerNorm-folded weights of all layers are kept at the front of the encoder workspace and the second and later
     encodes of the same ClipVitWeights on the same workspace skip the 2 x layers fold launches (TSPO_CLIP_FOLD_CACHED): the cached
-    call is bitwise the uncached one, a changed batch size / a new workspace / invalidate_fold_cache() fold again, and the
-    stand-alone LayerNorm path in between leaves the kept weights alone."""
+    call is bitwise the uncached one; a new workspace / invalidate_fold_cache() fold again; the stand-alone LayerNorm path in
+    between leaves the kept weights alone.  Round 6: the key no longer holds the batch size (a video encoded in
+    chunks with a shorter last chunk folds ONCE), a batch too small to fold neither uses nor sets the cache, and handing the raw
+    buffer out through the public `workspace()` ends the trust in it - an external write can no longer yield wrong features."""
     cfg = dict(synth.CLIP_L14)
     cfg["layers"] = 2
     W = ops.ClipVitWeights({k: T_(v) for k, v in synth.clip_vision_state(**cfg).items()}, cfg, DEV)
-    u8 = G_(synth.uniform_u8((64, 3, 224, 224), 78))
-    assert W._fold_key is None
-    f1 = ops.clip_vit_forward(W, u8)                      # folds
+    u8 = G_(synth.uniform_u8((80, 3, 224, 224), 78))
+    assert W._fold_key is None and W.library_folds(64) and W.library_folds(80) and not W.library_folds(8)
+    W._workspace(80)                                         # (the largest batch of this test first: one buffer throughout)
+    f1 = ops.clip_vit_forward(W, u8)                         # folds
     key = W._fold_key
     assert key is not None
-    f2 = ops.clip_vit_forward(W, u8)                      # cached
+    f2 = ops.clip_vit_forward(W, u8)                         # cached
     assert W._fold_key == key and torch.equal(f1, f2)
     f0 = ops.clip_vit_forward(W, u8, fold_layernorm=False)
-    f3 = ops.clip_vit_forward(W, u8)                      # still cached, still the same
+    f3 = ops.clip_vit_forward(W, u8)                         # still cached, still the same
     assert torch.equal(f1, f3) and (f0 - f1).abs().max().item() < 0.02 * f1.abs().max().item()
-    W.invalidate_fold_cache()
+    # another batch size that folds: the SAME key (chunked videos), same features for the shared frames
+    f64 = ops.clip_vit_forward(W, u8[:64])
+    assert W._fold_key == key and torch.equal(f64, f1[:64])
+    # a batch too small to fold takes the stand-alone LayerNorm kernels: cache neither used nor changed
+    f8 = ops.clip_vit_forward(W, u8[:8])
+    assert W._fold_key == key and (f8 - f1[:8]).abs().max().item() < 0.02 * f1.abs().max().item()
     assert torch.equal(ops.clip_vit_forward(W, u8), f1)
-    f65 = ops.clip_vit_forward(W, G_(synth.uniform_u8((65, 3, 224, 224), 78)))     # other batch size: new key (and a larger workspace)
-    assert W._fold_key != key and torch.equal(f65[:64], f1)
-    # a workspace full of NaN bytes with the flag forced would NOT be bitwise f1: the flag is really honoured
-    W.workspace(65).fill_(255)
-    W._fold_key = ops._fold_key(W, W.workspace(65), 64)
+    W.invalidate_fold_cache()
+    assert W._fold_key is None and torch.equal(ops.clip_vit_forward(W, u8), f1)
+    # the public accessor hands the raw buffer out: whatever the caller does to it, the next encode folds again
+    W.workspace(80).fill_(255)
+    assert W._fold_key is None
+    assert torch.equal(ops.clip_vit_forward(W, u8), f1)
+    # ... and the flag is really honoured: NaN bytes at the front with the trust forced back do NOT give f1
+    W._workspace(80).fill_(255)
+    W._fold_key = ops._fold_key(W, W._workspace(80), 80)
     assert not torch.equal(ops.clip_vit_forward(W, u8), f1)
     W.invalidate_fold_cache()
     assert torch.equal(ops.clip_vit_forward(W, u8), f1)
+    # library_folds mirrors the library: where it says "no fold", the forced flag changes nothing (the library ignores it)
+    W._workspace(80).fill_(255)
+    W._fold_key = None
+    assert torch.equal(ops.clip_vit_forward(W, u8[:8]), f8)
 
 
 def test_patch_gather_u8_staged_kernel_equals_the_generic_one():
@@ -781,21 +797,29 @@ def test_patch_gather_u8_staged_kernel_equals_the_generic_one():
     assert torch.isfinite(fa).all() and torch.equal(fa, fb)
 
 
-@pytest.mark.parametrize("n_frames", [64, 70])
-def test_residual_statistics_epilogue_against_the_stored_rows(n_frames):
+@pytest.mark.parametrize("n_frames,offset", [(64, 0.0), (70, 0.0), (70, 80.0)], ids=["64", "70", "70_rows_near_a_common_offset_of_80"])
+def test_residual_statistics_epilogue_against_the_stored_rows(n_frames, offset):
     """The residual + statistics epilogue of the production GEMM (GE_RESID_ST; round 5: residual rows added and row statistics
     formed on the matrix pipe) has no entry of its own in the C ABI - the encoder is its only caller - so it is checked where it
     runs: one CLIP-L/14 block with a zero fc2 (so that the residual stream after the block IS the out-proj's output, in place),
     LayerNorms folded: the per-row, per-64-column-slice (mean, centred sum of squares) pairs the out-proj's epilogue left in the
     workspace against the same statistics of the bf16 rows it stored.  64 frames = 64.25 row tiles, 70 frames = 70.27: the ragged
     tile runs through the 64x64 remainder sub-tiles (a second copy of the epilogue; round 5 found a VALU -> asm-MFMA hazard there
-    that only this comparison shows: the features of the class-token rows stayed finite).  Workspace layout: clip_carve() of
+    that only this comparison shows: the features of the class-token rows stayed finite).  offset = 80 (round 6): the
+    out-proj bias puts EVERY channel of the residual stream near 80 with a spread of ~0.1 - |mean| >> std, the case where the
+    one-pass M2 = sum x^2 - sum x . mean could cancel.  It does not, for a reason worth stating: the inputs are bf16 (8-bit
+    significands), so a slice whose values sit near a common offset shares ONE exponent, its 64 squares are 16-bit numbers on a
+    common grid and their fp32 sums are EXACT; what is left is the rounding of the one product sum x . mean (2^-24 of sum x^2).
+    Asserted: |M2 - ref| <= 4e-7 x sum x^2 per slice, the merged row variance within 1e-3 (measured on MI355X: both EXACT, 0.0 and
+    1.7e-15).  Workspace layout: clip_carve() of
     csrc/clip_vit.hip (the folded weights of all layers | x | h | qkv | a | u | patches | pooled | stats | spart, 256-byte aligned)."""
     cfg = dict(synth.CLIP_L14)
     cfg["layers"] = 1
     state = synth.clip_vision_state(**cfg)
     for k in ("mlp.fc2.weight", "mlp.fc2.bias"):
         state["vision_model.encoder.layers.0." + k] = np.zeros_like(state["vision_model.encoder.layers.0." + k])
+    if offset:
+        state["vision_model.encoder.layers.0.self_attn.out_proj.bias"] = (offset + synth.normal((cfg["hidden"],), 77, 0.1)).astype(np.float32)
     W = ops.ClipVitWeights({k: T_(v) for k, v in state.items()}, cfg, DEV)
     u8 = G_(synth.uniform_u8((n_frames, 3, 224, 224), 5 + n_frames))
     feat = ops.clip_vit_forward(W, u8, fold_layernorm=True)
@@ -821,11 +845,26 @@ def test_residual_statistics_epilogue_against_the_stored_rows(n_frames):
     m2 = ((xs - mean[..., None]) ** 2).sum(-1)
     dm = (sp[..., 0].double() - mean).abs().max().item()
     dq = ((sp[..., 1].double() - m2).abs() / m2.clamp_min(1e-3)).max().item()
-    print(f"\n[GE_RESID_ST statistics, {n_frames} frames] max |mean - ref| {dm:.2e}, max rel |M2 - ref| {dq:.2e}")
-    assert dm < 5e-6 and dq < 1e-4          # fp32 sums of 64 exact bf16 values / their exact squares: rounding of the sums only
+    sx2 = (xs ** 2).sum(-1)
+    da = ((sp[..., 1].double() - m2).abs() / sx2.clamp_min(1e-30)).max().item()
+    # the row variance the folded GEMMs use: Chan's merge of the 16 slices, here in float64 from the kernel's pairs vs from the rows
+    mu_k = sp[..., 0].double().mean(-1)
+    var_k = (sp[..., 1].double().sum(-1) + 64 * ((sp[..., 0].double() - mu_k[:, None]) ** 2).sum(-1)) / C
+    var_r = x.double().var(-1, unbiased=False)
+    dv = ((var_k - var_r).abs() / var_r.clamp_min(1e-12)).max().item()
+    print(f"\n[GE_RESID_ST statistics, {n_frames} frames, offset {offset}] max |mean - ref| {dm:.2e}, max rel |M2 - ref| {dq:.2e}, "
+          f"max |M2 - ref| / sum x^2 {da:.2e}, row variance rel. error {dv:.2e} (row mean |x| {x.abs().mean().item():.2f}, std {x.std(-1).mean().item():.3f})")
+    if offset:
+        assert dm < 2e-5 and da < 4e-7 and dv < 1e-3
+    else:
+        assert dm < 5e-6 and dq < 1e-4          # fp32 sums of 64 exact bf16 values / their exact squares: rounding of the sums only
     # and the stand-alone LayerNorm path (other kernels, same arithmetic up to bf16 rounding) ends in the same features
     feat0 = ops.clip_vit_forward(W, u8, fold_layernorm=False)
-    assert (feat - feat0).abs().max().item() < 0.02 * feat0.abs().max().item()
+    # (offset 80: the residual stream is STORED in bf16 - as in the reference - and near 80 one bf16 step is 0.5 = half a standard
+    #  deviation of these rows, so two numerically equivalent paths that round ONE element of the class-token row differently end
+    #  0.5 sigma apart in that channel after the final LayerNorm: measured 2.9 % of the feature range.  The statistics themselves
+    #  are exact there - asserted above - which is what this case is for.)
+    assert (feat - feat0).abs().max().item() < (0.1 if offset else 0.02) * feat0.abs().max().item()
 
 
 def test_clip_vit_forward_70_frames_production_kernels():

@@ -265,3 +265,31 @@ def test_reproduce_published_idx_tool_host_logic():
         assert key == join_key(ds) and key in d
         assert (video_of(d), m.problem_of(d)) == want[ds]
         assert FrameIdGenerator.problem_of("Question: " + m.problem_of(d) + "\nOptions") == want[ds][1]
+
+
+def test_batch_meta_is_per_prompt_stacked_or_not():
+    """a reward plug-in reading batch.meta must see ONE convention - a list with one entry per prompt - on a single
+    micro-batch and on the stacked batch of a coalesced accumulation window (tspo_amd.train._stack)."""
+    import pytest as _pt
+    from tspo_amd import train as TR
+
+    def mk(B, meta):
+        return TR.Batch(torch.zeros(B, 6, 4), torch.zeros(B, 1, 4), torch.zeros(B, 6), torch.ones(B, 6, dtype=torch.bool), "specific", meta)
+    a, b = mk(1, {"path": "a.pth"}), mk(1, [{"path": "b.pth"}])
+    assert a.meta == [{"path": "a.pth"}] and b.meta == [{"path": "b.pth"}] and mk(2, None).meta == [None, None]
+    st = TR._stack([a, b])
+    assert st.feats.shape[0] == 2 and st.meta == [{"path": "a.pth"}, {"path": "b.pth"}] and TR._stackable([a, b])
+    st2 = TR._stack([mk(2, [1, 2]), mk(2, [3, 4])])
+    assert st2.meta == [1, 2, 3, 4] and st2.feats.shape[0] == 4
+    with _pt.raises(ValueError):
+        mk(2, [1])
+    with _pt.raises(ValueError):
+        mk(2, {"path": "x"})
+    seen = []
+
+    def reward(idx, batch):           # a plug-in that indexes meta per prompt, as a video-LLM reward pass would (its video path)
+        seen.append([batch.meta[i] for i in range(idx.shape[0])])
+        return torch.zeros(idx.shape[0], idx.shape[1], 2)
+    reward(torch.zeros(2, 3, 2, dtype=torch.long), st)
+    reward(torch.zeros(1, 3, 2, dtype=torch.long), a)
+    assert seen == [[{"path": "a.pth"}, {"path": "b.pth"}], [{"path": "a.pth"}]]

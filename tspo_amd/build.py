@@ -22,6 +22,34 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+# The hand-placed wait states around inline-asm MFMAs (csrc/gemm_epilogue.h: `s_nop 3` in front, `s_nop 15; s_nop 7` behind) and the
+# literal-AGPR kernels were validated with THIS compiler; hipcc's hazard recogniser does not see MFMAs inside asm, and how it
+# materialises their operand tuples may change with the version or with extra flags.  A different toolchain is not an
+# error, but it must pass the post-build checks before its library is trusted:
+#   python -m pytest tests/test_abi.py -k "code_audit or dev_hooks"          (generated-code audit: no VALU write of an MFMA operand
+#                                                                             within two instructions, no compiler AGPR use, spills)
+#   python -m pytest tests -m gpu -k "remainder_phase_bitwise or residual_statistics or in_place"   (77-vs-83 bitwise, statistics, aliasing)
+VALIDATED_TOOLCHAIN = "roc-7.2.0"      # `hipcc --version`: AMD clang 22.0.0git ... roc-7.2.0 (HIP 7.2.26015)
+
+
+def toolchain_note(hipcc: str, flags) -> str:
+    """'' when the library is being built with the validated compiler and no extra flags, else what to run afterwards."""
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception as e:      # pragma: no cover
+        ver = f"(hipcc --version failed: {e})"
+    why = []
+    if VALIDATED_TOOLCHAIN not in ver:
+        why.append(f"hipcc is not the validated {VALIDATED_TOOLCHAIN} toolchain ({(ver.splitlines() or ['?'])[0]})")
+    if flags:
+        why.append(f"TSPO_EXTRA_HIPCC_FLAGS={' '.join(flags)}")
+    if not why:
+        return ""
+    return ("tspo_amd.build: " + "; ".join(why) + " - the wait states around the hand-written MFMAs were validated with the stock "
+            "compiler and flags: run `pytest tests/test_abi.py -k code_audit` and the bitwise GPU tests (see tspo_amd/build.py) "
+            "before trusting this library")
+
+
 DEV_SOURCES = ["dev/gemm_dma_lab.hip", "dev/gemm_agpr.hip"]      # compiled into the library only by build(dev=True) / `--dev`
 DEV_HEADERS = [os.path.join(CSRC, "dev", "gemm_dma_lab_kernel.h")]
 MODE_STAMP = LIB + ".mode"      # "product" | "dev": which build the .so on disk is (a dev library must never pass for the shipped one)
@@ -54,6 +82,9 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False, only=Non
         return LIB
     hipcc = _hipcc()
     flags = os.environ.get("TSPO_EXTRA_HIPCC_FLAGS", "").split()
+    note = toolchain_note(hipcc, flags)
+    if note:
+        print(note, file=sys.stderr, flush=True)
     sources = SOURCES + (DEV_SOURCES if dev else [])
 
     def compile_one(s):

@@ -398,11 +398,13 @@ class ClipVitWeights:
         self._fold_key = None   # (workspace, batch size, stream) the folded weights kept in the workspace are valid for
 
     def invalidate_fold_cache(self) -> None:
-        """Forget the LayerNorm-folded weights kept in the workspace (only needed by code that edits the packed weight tensors
-        in place - nothing in this package does)."""
+        """Forget the LayerNorm-folded weights kept in the workspace (needed by code that edits the packed weight tensors in place
+        - nothing in this package does; writing to the buffer `workspace()` hands out invalidates by itself)."""
         self._fold_key = None
 
-    def workspace(self, n_frames: int) -> torch.Tensor:
+    def _workspace(self, n_frames: int) -> torch.Tensor:
+        """The encoder's workspace as the LIBRARY uses it (caller-owned memory of the C ABI): the LayerNorm-folded weights of all
+        layers live at its front (0.35 GB for CLIP-L/14, offsets independent of the batch), the activations behind them."""
         n = _lib.lib().tspo_clip_workspace_bytes(C.byref(self.struct.cfg), n_frames)
         if n == 0:
             raise ValueError("clip: bad config")
@@ -411,6 +413,25 @@ class ClipVitWeights:
             self._fold_key = None
         return self._ws
 
+    def workspace(self, n_frames: int) -> torch.Tensor:
+        """The raw workspace buffer, for inspection (tests read the activations / statistics a forward left in it).  Handing it
+        out ends the library's exclusive use of it, so the kept folded weights are no longer trusted: the next encode folds again
+        (an external write to the front of the buffer must not silently yield wrong features)."""
+        ws = self._workspace(n_frames)
+        self._fold_key = None
+        return ws
+
+    def library_folds(self, n_frames: int) -> bool:
+        """Whether an encode of n_frames takes the LayerNorm-folded path at all (mirrors csrc/clip_vit.hip: both folded GEMMs must be
+        "big" problems, csrc/gemm_bf16.hip gemm_bf16_is_big - checked against the library's behaviour by tests/test_gpu_ops.py)."""
+        c = self.cfg
+        S = (c["image"] // c["patch"]) ** 2 + 1
+        M = n_frames * S
+
+        def big(N, K):
+            return M * N >= 256 ** 3 and K >= 128 and N <= 4096
+        return c["layers"] > 0 and big(c["hidden"], c["hidden"]) and big(c["hidden"], c["mlp"])
+
 
 def _clip_flags(fold_layernorm: bool, prune_last_layer: bool, fold_cached: bool = False) -> int:
     return ((0 if fold_layernorm else _lib.TSPO_CLIP_NO_LN_FOLD) | (_lib.TSPO_CLIP_PRUNE_LAST if prune_last_layer else 0) |
@@ -418,10 +439,13 @@ def _clip_flags(fold_layernorm: bool, prune_last_layer: bool, fold_cached: bool 
 
 
 def _fold_key(w, ws: torch.Tensor, n_frames: int):
-    """What the folded weights kept in a ClipVitWeights workspace are valid FOR: this buffer, this batch size (which decides
-    whether the library folds at all) and the stream they were written on.  The weights of a ClipVitWeights never change (a new
-    state dict makes a new object, and with it a new workspace)."""
-    return (ws.data_ptr(), ws.numel(), int(n_frames), torch.cuda.current_stream(ws.device).cuda_stream)
+    """What the folded weights kept in a ClipVitWeights workspace are valid FOR: this buffer and the stream they were written on -
+    NOT the batch size (the folded weights do not depend on it: a video encoded in chunks with a shorter last chunk folds once);
+    None when a batch of n_frames does not fold at all (nothing is written, nothing may be assumed).  The weights of a
+    ClipVitWeights never change (a new state dict makes a new object, and with it a new workspace)."""
+    if not w.library_folds(n_frames):
+        return None
+    return (ws.data_ptr(), ws.numel(), torch.cuda.current_stream(ws.device).cuda_stream)
 
 
 def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torch.Tensor] = None,
@@ -439,16 +463,16 @@ def clip_vit_forward(w: ClipVitWeights, pixels: torch.Tensor, out: Optional[torc
     cfg = w.cfg
     if tuple(px.shape[1:]) != (3, cfg["image"], cfg["image"]):
         raise ValueError(f"pixels must be [N,3,{cfg['image']},{cfg['image']}], got {tuple(px.shape)}")
-    ws = w.workspace(N)
+    ws = w._workspace(N)
     feat = out if out is not None else torch.empty((N, cfg["proj"]), dtype=torch.float32, device=px.device)
     # the LayerNorm-folded weights of all layers stay in the workspace between calls (TSPO_CLIP_FOLD_CACHED): the second and later
     # encodes of a frozen CLIP tower on the same workspace skip the 2 x layers fold launches
     key = _fold_key(w, ws, N)
-    cached = fold_layernorm and w._fold_key == key
+    cached = fold_layernorm and key is not None and w._fold_key == key
     check(_lib.lib().tspo_clip_vit_forward_ex(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
                                               ws.numel(), _stream(), _clip_flags(fold_layernorm, prune_last_layer, cached)),
           "tspo_clip_vit_forward")
-    if fold_layernorm:
+    if fold_layernorm and key is not None:
         w._fold_key = key
     return feat
 
@@ -458,15 +482,15 @@ def clip_vit_profile(w: ClipVitWeights, pixels: torch.Tensor, fold_layernorm: bo
     _need_gpu(pixels)
     px = pixels.contiguous()
     N = px.shape[0]
-    ws = w.workspace(N)
+    ws = w._workspace(N)
     feat = torch.empty((N, w.cfg["proj"]), dtype=torch.float32, device=px.device)
     ms = (C.c_float * 6)()
     key = _fold_key(w, ws, N)
-    cached = fold_layernorm and w._fold_key == key
+    cached = fold_layernorm and key is not None and w._fold_key == key
     check(_lib.lib().tspo_clip_vit_profile(C.byref(w.struct), _ptr(px), _PIX_DTYPES[px.dtype], N, _ptr(feat), _ptr(ws),
                                            ws.numel(), _stream(), ms, _clip_flags(fold_layernorm, False, cached)),
           "tspo_clip_vit_profile")
-    if fold_layernorm:
+    if fold_layernorm and key is not None:
         w._fold_key = key
     return {"gemm_ms": ms[0], "attn_ms": ms[1], "ln_ms": ms[2], "gather_ms": ms[3], "total_ms": ms[4],
             "gemm_launches": int(ms[5])}

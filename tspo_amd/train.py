@@ -64,9 +64,19 @@ class TrainConfig:
 
 
 class Batch:
-    """One micro-batch of prompts on this rank: features [B,T,D], text [B,1,D], clip [B,T], mask [B,T] bool, type."""
+    """One micro-batch of prompts on this rank: features [B,T,D], text [B,1,D], clip [B,T], mask [B,T] bool, type, and `meta`:
+    ALWAYS a list of length B - entry b describes prompt b (e.g. {"path": ...} of its feature cache; None when the data set has
+    nothing to say).  The same convention holds for a single micro-batch and for the stacked batch of a coalesced accumulation
+    window (round 6, ADVICE r5: a reward plug-in that reads `batch.meta[b]` sees the same thing on stacked and unstacked steps)."""
 
     def __init__(self, feats, txt, clip, mask, item_type="specific", meta=None):
+        B = feats.shape[0]
+        if meta is None:
+            meta = [None] * B
+        elif not isinstance(meta, list):
+            meta = [meta] * B if B == 1 else None
+        if meta is None or len(meta) != B:
+            raise ValueError(f"Batch.meta must be a list with one entry per prompt (B={B})")
         self.feats, self.txt, self.clip, self.mask, self.item_type, self.meta = feats, txt, clip, mask, item_type, meta
 
 
@@ -129,11 +139,15 @@ def _stackable(window: List[Batch]) -> bool:
 
 def _stack(window: List[Batch]) -> Batch:
     return Batch(torch.cat([b.feats for b in window]), torch.cat([b.txt for b in window]), torch.cat([b.clip for b in window]),
-                 torch.cat([b.mask for b in window]), window[0].item_type, [b.meta for b in window])
+                 torch.cat([b.mask for b in window]), window[0].item_type, [m for b in window for m in b.meta])
 
 
 def mask_reward_model(idx: torch.Tensor, batch: Batch) -> torch.Tensor:
-    """Default reward plug-in -> rewards_per_func [B, G, 2] = (accuracy proxy, temporal localisation).  The temporal
+    """Default reward plug-in -> rewards_per_func [B, G, 2] = (accuracy proxy, temporal localisation).
+    The plug-in contract (what `train(reward_model=...)` calls - the frozen video-LLM pass of tspo_trainer.py:554-573 lives behind
+    it): `reward_model(idx [B,G,k] int64 ascending, batch) -> [B, G, F] float`, where `batch` holds B prompts - ONE micro-batch, or
+    the stacked micro-batches of a coalesced accumulation window (then B = accum x per-device batch) - and `batch.meta[b]` is prompt
+    b's meta in BOTH cases.  Rows of `idx`, `batch.feats`, `batch.mask` and `batch.meta` correspond.  The temporal
     column is the reference's reward (tspo.py:146-159); the accuracy column stands in for the frozen video-LLM's answer
     check: 1 when at least 40 % of the selected frames are relevant (the iou gate left commented at tspo.py:131-134)."""
     temporal = rewards.selection_mask_reward_gpu(idx, batch.mask)
