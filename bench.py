@@ -685,6 +685,12 @@ def main():
 
     sel_sec = timed(select_step, max(a.steps, 200), 3) / max(a.steps, 200)
     assert torch.equal(out["idx2"], out["idx"])
+    # the same stage at the reference's own inference precision (gen_id_tspo.py:55 loads the scoring head in bf16): bf16 GEMM operands,
+    # fp32 accumulation (TSPO_SEL_BF16) - opt-in, NOT used for `value`; how many of the fp32 path's k indices it keeps is reported
+    scorer.selector_precision = "bf16"
+    sel16_sec = timed(select_step, max(a.steps, 200), 3) / max(a.steps, 200)
+    keep16 = sum(len(set(x) & set(y)) for x, y in zip(out["idx2"].tolist(), out["idx"].tolist())) / max(1, out["idx"].numel())
+    scorer.selector_precision = "fp32"
 
     # ---- rollouts / s (policy side of one TSPO step, configs[2]) --------------
     rollouts = rollouts_x3 = dp_path = None
@@ -795,7 +801,10 @@ def main():
                 "note": "opt-in ops.clip_vit_forward(prune_last_layer=True): last block for the class-token row only "
                         "(same features); not used for `value`"},
             "frames_scored_per_s_from_720p_u8": from_720p,
-            "split_ms": {"encode": round(sec / a.steps * 1e3 - sel_sec * 1e3, 3), "score_select": round(sel_sec * 1e3, 3)},
+            "split_ms": {"encode": round(sec / a.steps * 1e3 - sel_sec * 1e3, 3), "score_select": round(sel_sec * 1e3, 3),
+                         "score_select_bf16_operands": round(sel16_sec * 1e3, 3), "bf16_keeps_fraction_of_fp32_topk": round(keep16, 4),
+                         "note": "score_select = clip cosine + scoring head + top-k on resident features, exact fp32 (used for `value`); "
+                                 "_bf16_operands = the same with FrameScorer(selector_precision='bf16'), the reference's inference precision"},
             "roofline": roof, "cpu_baseline": cpu, "comm": comm,
             "launcher": "torch.distributed.run" if (world > 1 and not os.environ.get("TSPO_SELF_SPAWNED")) else
                         ("self-spawn" if world > 1 else "single process"),

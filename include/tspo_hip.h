@@ -180,6 +180,13 @@ int tspo_selector_backward(const tspo_selector_weights* w, const float* img, con
  * train_deepspeed.sh:31) without a scratch bucket and an add pass.          */
 #define TSPO_SEL_BF16X3 1
 #define TSPO_SEL_ACCUMULATE 2
+/* TSPO_SEL_BF16 (tspo_selector_forward_ex only; round 6): the reference's own INFERENCE precision as a first-class path - it loads the
+ * scoring head in bf16 (mp_tools/vlmeval/vlm/gen_id_tspo.py:55, tspo_trainer.py:201): the three projections and the two MLP
+ * layers take their operands rounded to bf16 (round-to-nearest-even, in registers) with fp32 accumulation on the bf16 MFMA,
+ * ONE matrix instruction where the exact mode issues eight; everything between the GEMMs (position add, banded softmax,
+ * ReLU, residual, cosine) stays fp32 - fewer roundings than the reference's bf16 module, whose every intermediate is bf16.
+ * Not for the greedy-index parity claims (those use flags = 0) and not accepted by the backward calls. */
+#define TSPO_SEL_BF16 4
 int tspo_selector_forward_ex(const tspo_selector_weights* w, const float* img, const float* txt, const float* clip,
                              int B, int T, int D, int H, int M, int window, float tau,
                              float* scores, float* temporal_attn,

@@ -500,6 +500,69 @@ def test_selector_bf16x3_split_precision_vs_exact():
         ops.selector_forward(flat, img, txt, clip, H, w, tau, precision="fp16")
 
 
+def _selector_forward_bf16_operands_emulated(state, img, txt, clip, w, tau, H):
+    """What TSPO_SEL_BF16 computes, on the CPU: the oracle's forward (oracle/tspo_oracle.py: selector_forward) with the operands of
+    the five dense layers - and only those - rounded to bf16 (round-to-nearest-even), fp32 accumulation, fp32 everywhere else."""
+    import torch.nn.functional as F
+    r = lambda t: t.to(torch.bfloat16).float()
+    p = {k: T_(v) for k, v in state.items()}
+    x = T_(img)[None]
+    T, D = img.shape
+    hd = D // H
+    x_t = x + O.positional_encoding(T, D)
+    lin = lambda a, n: F.linear(r(a), r(p[n + ".weight"]), p[n + ".bias"])
+    q, k, v = (lin(x_t, "temporal.Self_" + c).view(1, T, H, hd).permute(0, 2, 1, 3) for c in "qkv")
+    sc = (torch.matmul(q, k.transpose(-2, -1)) / hd ** 0.5).masked_fill(O.create_window_mask(T, w) == 0, -1e6)
+    ctx = torch.matmul(F.softmax(sc, dim=-1), v).transpose(1, 2).contiguous().view(1, T, D)
+    h = lin(F.relu(lin(ctx, "mlp.0")), "mlp.2") + x
+    return (O.pair_cosine(h, T_(txt)[None])[0].mean(-1) + T_(clip)) / tau, h
+
+
+@pytest.mark.parametrize("case", [c for c in SELECTOR_CASES if c[0] in ("s32", "s40m3", "s300", "s1024")], ids=lambda c: c[0])
+def test_selector_bf16_operand_inference_precision(golden, case):
+    """TSPO_SEL_BF16 (round 6): the reference's own inference precision as a first-class path - it loads the scoring head in bf16
+    (gen_id_tspo.py:55).  (1) The kernel computes exactly 'operands rounded to bf16, fp32 accumulate, fp32 between the GEMMs':
+    scores and h against that arithmetic on the CPU to fp32 summation-order tolerance.  (2) Against the fp32 golden it sits
+    INSIDE the reference's own bf16-vs-fp32 noise on the same inputs (tests/golden/bf16_noise.json: the imported MultiModal_Align
+    cast to bf16, which also rounds every intermediate) - the criterion of test_multimodal_align_bf16_like_reference's report.
+    (3) The option really switches kernels, is forward-only, and excludes bf16x3."""
+    name, T, D, H, w, tau, M, ks = case
+    img, txt, clip, state = selector_inputs(name, T, D, M)
+    flat = flat_from_state(state, D)
+    s16, h16, ws16 = ops.selector_forward(flat, G_(img[None]), G_(txt[None]), G_(clip[None]), H, w, tau, precision="bf16")
+    s32, h32, _ = ops.selector_forward(flat, G_(img[None]), G_(txt[None]), G_(clip[None]), H, w, tau)
+    assert not torch.equal(s16, s32)
+    s_em, h_em = _selector_forward_bf16_operands_emulated(state, img, txt, clip, w, tau, H)
+    # (an intermediate - ctx, the ReLU output - that differs by one fp32 ulp between the GPU and the CPU can fall on the other side of
+    #  a bf16 rounding boundary and move ONE term of a later dot product by 2^-9: a handful of elements sit ~1e-4 (cosine units)
+    #  off; everything else agrees to fp32 summation order)
+    ds = np.abs(s16[0].cpu().numpy() - s_em.numpy())
+    tight = 5e-5 * np.abs(s_em.numpy()) + 5e-5 / tau
+    assert (ds > tight).mean() <= 0.01 and ds.max() <= 4e-4 / tau, ((ds > tight).sum(), ds.max())
+    dh = np.abs(h16[0].cpu().numpy() - h_em[0].numpy())
+    hmax = np.abs(h_em[0].numpy()).max()
+    assert dh.mean() <= 2e-5 * hmax and dh.max() <= 2e-3 * hmax, (dh.mean() / hmax, dh.max() / hmax)   # (bf16 operand noise itself: ~4e-3 hmax)
+    ref = golden["selector"][f"{name}.scores"]
+    err16 = np.abs(s16[0].cpu().numpy() - ref).max()
+    noise = _ref_bf16_noise()["selector"][name]["score_eps_logits"]
+    print(f"\n[selector bf16 operands, {name}] |score - fp32 golden| {err16:.4f} logits vs the reference's own bf16 module {noise:.4f} "
+          f"(x{err16 / noise:.2f}); exact-fp32 HIP path {np.abs(s32[0].cpu().numpy() - ref).max():.2e}")
+    assert err16 <= noise, f"bf16-operand scores {err16} logits from fp32, the reference's own bf16 path {noise}"
+    k = min(32, T)
+    keep = len(set(ops.topk_sorted(s16[0], k).cpu().tolist()) & set(ops.topk_sorted(s32[0], k).cpu().tolist()))
+    assert keep >= k - max(2, k // 8), f"top-{k}: bf16 operands keep {keep} of the fp32 path's indices"
+    with pytest.raises(ValueError):
+        ops.selector_backward(flat, torch.zeros_like(flat), G_(img[None]), G_(txt[None]), G_(clip[None]), H, w, tau, ws16, precision="bf16")
+    from tspo_amd import _lib
+    import ctypes as C
+    wst = ops._sel_structs(flat, D, _lib.SelectorWeights)
+    ws = ops.selector_workspace(1, T, D, H, M, w, flat.device)
+    sc = torch.empty((1, T), device=DEV)
+    rc = _lib.lib().tspo_selector_forward_ex(C.byref(wst), ops._ptr(G_(img[None])), ops._ptr(G_(txt[None])), ops._ptr(G_(clip[None])), 1, T, D, H, M,
+                                             w, float(tau), ops._ptr(sc), None, ops._ptr(ws), ws.numel(), ops._stream(), 1 | 4)
+    assert rc != 0 and b"exclusive" in _lib.lib().tspo_last_error()
+
+
 def test_selector_fwd_bwd_bitwise_repeatable():
     """Race screen for the LDS-DMA ring GEMMs / MFMA banded attention: the same inputs must give bit-identical scores and
     gradients every time (fixed-order split reductions, counted vmcnt waits) at the policy-step shape of the bench."""

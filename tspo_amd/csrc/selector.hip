@@ -30,6 +30,15 @@ __device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf
   lo = l.v;
 }
 
+// bf16 operands, fp32 accumulation (TSPO_SEL_BF16, inference): the operand rounded to nearest-even bf16 - what a bf16 model holds
+// (gen_id_tspo.py:55) - one MFMA per 32-deep slab; products of bf16 values are exact in the fp32 accumulator.
+__device__ __forceinline__ bf16x8 round_bf16x8(const float (&x)[8]) {
+  union { bf16x8 v; uint32_t u[4]; } h;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h.u[j] = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+  return h.v;
+}
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -263,7 +272,27 @@ __device__ __forceinline__ void gemm_f32_nt_lds_body(char* lds, const float* __r
 #pragma unroll
     for (int sub = 0; sub < SPB; ++sub) {
     const char* cur = lds + (ring_now * SPB + sub) * SLAB;
-    if (SPLIT) {
+    if (SPLIT == 2) {
+      // bf16 operands / fp32 accumulate (TSPO_SEL_BF16): the slab's fp32 values rounded to bf16 in registers, ONE MFMA per tile and slab
+      const int c0 = (((2 * q) ^ sw) << 4), c1 = (((2 * q + 1) ^ sw) << 4);
+      bf16x8 ah[MI], bh[WN];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(cur + offA[i] + c0), v = *reinterpret_cast<const f32x4*>(cur + offA[i] + c1);
+        const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        ah[i] = round_bf16x8(x);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(cur + offW[j] + c0), v = *reinterpret_cast<const f32x4*>(cur + offW[j] + c1);
+        const float x[8] = {u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+        bh[j] = round_bf16x8(x);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    } else if (SPLIT) {
       // one bf16 MFMA spans the whole 32-deep slab: lane (row l15, q) owns k = 8q..8q+7 = 16-byte chunks 2q, 2q+1
       const int c0 = (((2 * q) ^ sw) << 4), c1 = (((2 * q + 1) ^ sw) << 4);
       bf16x8 ah[MI], al[MI], bh[WN], bl[WN];
@@ -382,8 +411,9 @@ int launch_gemm_nt_p(const float* A, const float* W, const float* bias, const fl
 }
 template <int EPI>
 int launch_gemm_nt(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
-                   hipStream_t st, bool split = false) {
-  return split ? launch_gemm_nt_p<EPI, 1>(A, W, bias, R, C, M, N, K, st) : launch_gemm_nt_p<EPI, 0>(A, W, bias, R, C, M, N, K, st);
+                   hipStream_t st, int split = 0) {   // 0 exact fp32, 1 bf16x3 (hi/lo split), 2 bf16 operands
+  if (split == 2 && K % 32 == 0) return launch_gemm_nt_p<EPI, 2>(A, W, bias, R, C, M, N, K, st);
+  return split == 1 ? launch_gemm_nt_p<EPI, 1>(A, W, bias, R, C, M, N, K, st) : launch_gemm_nt_p<EPI, 0>(A, W, bias, R, C, M, N, K, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -1734,8 +1764,10 @@ static int selector_forward_impl(const tspo_selector_weights* w, const float* im
                                  const float* clip, int B, int T, int D, int H, int M, int window, float tau,
                                  float* scores, float* temporal_attn, void* workspace, size_t workspace_bytes,
                                  tspo_stream_t stream, int flags) {
-  const bool split = (flags & TSPO_SEL_BF16X3) != 0;
-  TSPO_REQUIRE((flags & ~TSPO_SEL_BF16X3) == 0, "selector_forward: unknown flags 0x%x", flags);
+  TSPO_REQUIRE((flags & ~(TSPO_SEL_BF16X3 | TSPO_SEL_BF16)) == 0, "selector_forward: unknown flags 0x%x", flags);
+  TSPO_REQUIRE((flags & (TSPO_SEL_BF16X3 | TSPO_SEL_BF16)) != (TSPO_SEL_BF16X3 | TSPO_SEL_BF16), "selector_forward: TSPO_SEL_BF16X3 and TSPO_SEL_BF16 are exclusive");
+  TSPO_REQUIRE(!(flags & TSPO_SEL_BF16) || D % 32 == 0, "selector_forward: TSPO_SEL_BF16 needs D %% 32 == 0 (D=%d)", D);
+  const int split = (flags & TSPO_SEL_BF16) ? 2 : ((flags & TSPO_SEL_BF16X3) ? 1 : 0);
   TSPO_REQUIRE(w && img && txt && scores && workspace, "selector_forward: null pointer");
   TSPO_REQUIRE(w->wqkv && w->bqkv && w->w1 && w->b1 && w->w2 && w->b2, "selector_forward: null weight pointer");
   if (int e = check_dims("selector_forward", B, T, D, H, M, window)) return e;

@@ -205,15 +205,18 @@ def selector_workspace(B, T, D, H, M, window, device) -> torch.Tensor:
 
 SEL_BF16X3 = 1       # include/tspo_hip.h: TSPO_SEL_BF16X3
 SEL_ACCUMULATE = 2   # include/tspo_hip.h: TSPO_SEL_ACCUMULATE (backward calls: add to the gradient buffers)
+SEL_BF16 = 4         # include/tspo_hip.h: TSPO_SEL_BF16 (forward only: bf16 GEMM operands, fp32 accumulate - the reference's inference precision)
 
 
-def _sel_flags(precision: str, accumulate: bool = False) -> int:
+def _sel_flags(precision: str, accumulate: bool = False, forward: bool = False) -> int:
     acc = SEL_ACCUMULATE if accumulate else 0
     if precision == "fp32":
         return acc
     if precision == "bf16x3":
         return SEL_BF16X3 | acc
-    raise ValueError(f"selector precision must be 'fp32' or 'bf16x3', got {precision!r}")
+    if precision == "bf16" and forward:
+        return SEL_BF16
+    raise ValueError(f"selector precision must be 'fp32' or 'bf16x3' (forward / inference also 'bf16'), got {precision!r}")
 
 
 def selector_forward(flat: torch.Tensor, img: torch.Tensor, txt: torch.Tensor, clip: Optional[torch.Tensor],
@@ -221,7 +224,9 @@ def selector_forward(flat: torch.Tensor, img: torch.Tensor, txt: torch.Tensor, c
                      precision: str = "fp32"):
     """flat: f32 parameter bucket (FLAT_LAYOUT). img [B,T,D], txt [B,M,D], clip [B,T] ->
     (scores [B,T] f32, temporal_attn [B,T,D] f32 | None, workspace).
-    precision="bf16x3" (opt-in, training): split-precision GEMMs on the bf16 MFMA, ~1e-5 relative error."""
+    precision="bf16x3" (opt-in, training): split-precision GEMMs on the bf16 MFMA, ~1e-5 relative error.
+    precision="bf16" (opt-in, inference): the reference's own inference precision (gen_id_tspo.py:55) - GEMM operands rounded to
+    bf16, fp32 accumulation, fp32 between the GEMMs; a workspace written by it is NOT valid for a backward."""
     _need_gpu(flat, img, txt, clip)
     assert flat.dtype == torch.float32 and flat.is_contiguous()
     x, e = _f32c(img), _f32c(txt)
@@ -235,7 +240,7 @@ def selector_forward(flat: torch.Tensor, img: torch.Tensor, txt: torch.Tensor, c
     w = _sel_structs(flat, D, _lib.SelectorWeights)
     check(_lib.lib().tspo_selector_forward_ex(C.byref(w), _ptr(x), _ptr(e), _ptr(c), B, T, D, H, M, int(window), float(tau),
                                               _ptr(scores), _ptr(attn), _ptr(ws), ws.numel(), _stream(),
-                                              _sel_flags(precision)), "tspo_selector_forward")
+                                              _sel_flags(precision, forward=True)), "tspo_selector_forward")
     return scores, attn, ws
 
 

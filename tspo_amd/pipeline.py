@@ -23,7 +23,11 @@ from . import ops
 class FrameScorer:
     def __init__(self, clip_weights: ops.ClipVitWeights, selector_flat: torch.Tensor, dim: int = 768, heads: int = 8,
                  window_size: int = 12, score_tau: float = 0.025, fold_layernorm: bool = True,
-                 prune_last_layer: bool = False):
+                 prune_last_layer: bool = False, selector_precision: str = "fp32"):
+        # selector_precision: "fp32" (default; greedy indices identical to the fp32 oracle) or "bf16" - the reference's own inference
+        # precision (gen_id_tspo.py:55): bf16 GEMM operands, fp32 accumulation (ops.selector_forward(precision="bf16"))
+        ops._sel_flags(selector_precision, forward=True)
+        self.selector_precision = selector_precision
         self.clip, self.flat = clip_weights, selector_flat
         self.dim, self.heads, self.window, self.tau = dim, heads, window_size, score_tau
         self.fold_layernorm, self.prune_last_layer = fold_layernorm, prune_last_layer   # encoder options (ops.clip_vit_forward)
@@ -54,7 +58,7 @@ class FrameScorer:
         if self._sel_ws is None or self._sel_ws.numel() < need:
             self._sel_ws = torch.empty((need,), dtype=torch.uint8, device=feats.device)
         scores, _, _ = ops.selector_forward(self.flat, feats, text_features, clip_scores, self.heads, self.window,
-                                            self.tau, want_attn=False, ws=self._sel_ws)
+                                            self.tau, want_attn=False, ws=self._sel_ws, precision=self.selector_precision)
         return scores, clip_scores
 
     def __call__(self, pixels: torch.Tensor, text_features: torch.Tensor, k: int, method: str = "topk"):

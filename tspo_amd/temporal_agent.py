@@ -102,6 +102,11 @@ class MultiModal_Align(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(), nn.Linear(dim, dim))
         self._flat: Optional[torch.Tensor] = None
         self._flat_grad: Optional[torch.Tensor] = None
+        # inference-time GEMM precision (not a constructor argument: the reference's signature stays): "fp32" (default - exact fp32
+        # MFMA on the parameter VALUES, the mode of every greedy-index parity claim) or "bf16" (the reference's own inference
+        # precision, gen_id_tspo.py:55: bf16 GEMM operands, fp32 accumulation - ops.selector_forward(precision="bf16")).
+        # Training (grad mode) always runs exact fp32 unless PolicyTrainer(gemm_precision="bf16x3") is used.
+        self.inference_gemm_precision = "fp32"
         self._cache_key = None
         self._cache_flat = None
 
@@ -233,7 +238,7 @@ class MultiModal_Align(nn.Module):
             self._realias_grads()
             return _SelectorFn.apply(self, img, txt, clip, int(window_size), float(score_tau), *params)
         scores, attn, _ = ops.selector_forward(self._flat_params(), img, txt, clip, self.num_heads, int(window_size),
-                                               float(score_tau))
+                                               float(score_tau), precision=self.inference_gemm_precision)
         return scores, attn
 
 
