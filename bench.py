@@ -514,6 +514,7 @@ def main():
                     help="configs[4] long-form option (SURVEY 8e): ONE --frames video per step, its frames sharded over the N ranks for the "
                          "encode (FrameScorer.encode(shard_frames=True)), one all-gather of the features, replicated selector + top-k; "
                          "value = frames of that one video / s (STRONG scaling)")
+    ap.add_argument("--no-long-form", action="store_true", help="N > 1: skip the extra (non-headline) sharded 4096-frame video measurement")
     ap.add_argument("--no-comm-probe", action="store_true", help="skip the RCCL probe (init + timed all-reduce of the gradient bucket)")
     a = ap.parse_args()
 
@@ -676,6 +677,30 @@ def main():
         assert bool((out["idx720"][:, 1:] > out["idx720"][:, :-1]).all())
         del raw
 
+    # ---- N > 1, non-headline: configs[4]'s long-form option measured in the SAME launch (the driver's scaling run only passes
+    #      --gpus / --steps / --warmup): ONE 4096-frame video per step, frames sharded over the N ranks for the encode, one all-gather,
+    #      replicated scoring head + top-k -> a STRONG-scaling frames/s point per N; `--shard-frames` makes it the headline ----
+    long_form = None
+    if world > 1 and not shard and not a.no_long_form:
+        try:
+            TL = 4096
+            gl = torch.Generator(device=dev).manual_seed(40960)          # the same video on every rank
+            pxl = torch.randint(0, 256, (1, TL, 3, c["image"], c["image"]), generator=gl, device=dev, dtype=torch.uint8)
+
+            def long_step():
+                f = scorer.encode(pxl, shard_frames=True)
+                sc, _ = scorer.score(f, txt[:1])
+                out["idx_long"] = ops.topk_sorted(sc, k)
+
+            nl = max(2, a.steps // 2)
+            lsec = timed(long_step, nl, 1)
+            long_form = {"frames_scored_per_s": round(TL * nl / lsec, 2), "ms_per_video": round(lsec / nl * 1e3, 3), "frames_per_video": TL,
+                         "frames_per_gpu": -(-TL // world), "steps": nl, "scaling": "strong",
+                         "workload": workload_name(TL, 1, k, world, True)}
+            del pxl
+        except Exception as e:
+            long_form = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- split: score + select only (features resident), SURVEY 8(d) ----------
     feats_res = scorer.encode(pixels, shard_frames=shard)
 
@@ -801,6 +826,7 @@ def main():
                 "note": "opt-in ops.clip_vit_forward(prune_last_layer=True): last block for the class-token row only "
                         "(same features); not used for `value`"},
             "frames_scored_per_s_from_720p_u8": from_720p,
+            "configs4_long_form_sharded": long_form,
             "split_ms": {"encode": round(sec / a.steps * 1e3 - sel_sec * 1e3, 3), "score_select": round(sel_sec * 1e3, 3),
                          "score_select_bf16_operands": round(sel16_sec * 1e3, 3), "bf16_keeps_fraction_of_fp32_topk": round(keep16, 4),
                          "note": "score_select = clip cosine + scoring head + top-k on resident features, exact fp32 (used for `value`); "

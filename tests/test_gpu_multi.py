@@ -57,6 +57,9 @@ def test_bench_self_spawns_two_ranks_from_a_bare_shell():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["launcher"] == "self-spawn" and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0 and line["rollouts_per_s"] > 0 and line["steps"] == 2
+    lf = line["configs4_long_form_sharded"]            # N > 1: the strong-scaling point of configs[4] rides in the default launch
+    assert lf and "error" not in lf and lf["frames_per_video"] == 4096 and lf["frames_per_gpu"] == 2048 and lf["frames_scored_per_s"] > 0
+    assert lf["scaling"] == "strong" and lf["workload"].startswith("configs[4] long-form option")
     by_rank = line["ms_per_step_by_rank"]             # every rank's own clock over the timed region: a slow rank must be visible
     assert len(by_rank) == 2 and all(t > 0 for t in by_rank) and abs(max(by_rank) - line["ms_per_step"]) < 1e-3 * line["ms_per_step"] + 1e-3
     comm = line["comm"]
