@@ -3,7 +3,7 @@
 # per-GPU share, kernel traces of the policy step (B = 4 fused; the reference's B = 1 x 2 window sequential and coalesced),
 # then tools/prof_round.sh (kernel trace + FETCH/WRITE + SQ passes of the bench command).   tools/gpu_final.sh <tag>
 export TMPDIR=/tmp
-TAG=${1:-r5z}
+TAG=${1:-r6z}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $OUT/pytest_gpu.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > $OUT/smoke.log
