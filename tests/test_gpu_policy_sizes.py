@@ -43,7 +43,7 @@ def _bucket(grad, D):
     return {pn: g[offs[pn][0]:offs[pn][0] + int(np.prod(offs[pn][1]))].copy() for pn in O.SELECTOR_KEYS}
 
 
-def _check_update(name, g, trainer, flat0, bucket, D, scale_expected=None):
+def _check_update(name, g, trainer, flat0, bucket, D):
     """clip norm + the parameters after ONE AdamW step (lr 5e-4, HF defaults) against the fixture."""
     tn = float(g[f"{name}.gradnorm"])
     offs = ops.flat_offsets(D)
@@ -58,7 +58,7 @@ def _check_update(name, g, trainer, flat0, bucket, D, scale_expected=None):
         assert ok.sum() > ref.size // 2, pn
         np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-4, atol=2e-6, err_msg=f"{name}: {pn} after AdamW")
         assert not np.array_equal(got, flat0[off:off + ref.size].cpu().numpy()), f"{pn} was not updated"
-    o, shp = offs["temporal.ffn_o.weight"]
+    o, _ = offs["temporal.ffn_o.weight"]
     assert torch.equal(trainer.flat[o:o + D * D], flat0[o:o + D * D]), "ffn_o must never be updated (SURVEY a13)"
 
 
