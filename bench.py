@@ -815,7 +815,7 @@ def main():
             "rollouts_config": None if rollouts is None else {
                 "workload": ("policy step (reward LLM excluded): " + (
                     ("configs[2] (B=4/GPU, T=512, G=8, k=16, 1 GPU)" if world == 1 else
-                     f"configs[3] (B=4/GPU, T=512, G=8, k=16 on {world} GPUs: global batch {Bt * world} prompts, ONE RCCL all-reduce of the "
+                     f"configs[3] (B=4/GPU, T=512, G=8, k=16 on {world} GPUs: global batch {Bt * world} prompts, ONE {'RCCL' if a.backend == 'nccl' else a.backend} all-reduce of the "
                      f"11.8 MB bucket per optimizer step)") if (Bt, Tt, G, kt) == (4, 512, 8, 16) else
                     (f"configs[4] policy side (B={Bt}/GPU, T=4096, G=16, k=16 on {world} GPU(s))" if (Tt, G, kt) == (4096, 16, 16) else "custom"))),
                 "B": Bt, "T": Tt, "G": G, "k": kt, "global_batch_prompts": Bt * world, "ranks": world},
