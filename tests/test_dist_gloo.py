@@ -138,3 +138,28 @@ def test_shard_prompts_covers_everything():
         for w in (1, 2, 4, 8):
             got = [i for r in range(w) for i in shard_prompts(n, w, r)]
             assert got == list(range(n))
+
+
+def test_self_spawn_retries_once_on_a_rendezvous_error_only(tmp_path):
+    """The launcher finds its rendezvous port by binding and releasing it; when another process takes the port in between, rank 0's
+    store cannot listen ("address already in use").  self_spawn starts the ranks ONCE more on a fresh port for exactly that class
+    of failure; a rank's own error is returned at once (no second attempt)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    marker = tmp_path / "first_attempt_done"
+    prog = tmp_path / "prog.py"
+    prog.write_text("import os, sys\n"
+                    f"m = {str(marker)!r}\n"
+                    "if os.environ['RANK'] == '0' and not os.path.exists(m):\n"
+                    "    open(m, 'w').close()\n"
+                    "    sys.stderr.write('RuntimeError: The server socket has failed to listen on any local network address. "
+                    "port: 29511, useIpv6: false, code: -98, name: EADDRINUSE, message: address already in use\\n'); sys.exit(1)\n"
+                    "sys.exit(0)\n")
+    code = ("import sys; sys.path.insert(0, %r); from tspo_amd import dist as d; sys.exit(d.self_spawn(2, [%r], timeout=60))" % (root, str(prog)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "starting the 2 ranks once more on a new port" in r.stderr, r.stderr[-2000:]
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys\nsys.stderr.write('ValueError: my own bug\\n'); sys.exit(5 if os.environ['RANK'] == '1' else 0)\n")
+    code2 = code.replace(str(prog), str(bad))
+    r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=180)
+    assert r2.returncode == 5 and "once more" not in r2.stderr

@@ -34,6 +34,19 @@ def _clean_env():
     return env
 
 
+def _ok(r, tag):
+    """returncode == 0, else the child's whole stderr goes to gpurun_out/failed_<tag>.stderr (merged back by gpurun: a failure that
+    shows once in many runs can be read afterwards) and its tail into the assertion message."""
+    if r.returncode != 0:
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"failed_{tag}.stderr"), "w") as f:
+                f.write(r.stderr + "\n---- stdout ----\n" + r.stdout)
+        except OSError:
+            pass
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 def _json_lines(text):
     out = []
     for ln in text.splitlines():
@@ -51,7 +64,7 @@ def test_bench_self_spawns_two_ranks_from_a_bare_shell():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
                         "--frames", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pruned"],
                        env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    _ok(r, "bench_self_spawn_2ranks")
     lines = [l for l in _json_lines(r.stdout) if "metric" in l]
     assert len(lines) == 1, r.stdout[-2000:]
     line = lines[0]
@@ -77,7 +90,7 @@ def test_bench_shard_frames_two_ranks_strong_scaling_line():
             "--no-pruned", "--no-720p", "--no-rollouts", "--no-comm-probe"]
     r = subprocess.run(base + ["--gpus", "2", "--same-device", "--backend", "gloo", "--shard-frames"],
                        env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    _ok(r, "bench_shard_frames_2ranks")
     line = [l for l in _json_lines(r.stdout) if "metric" in l][0]
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["launcher"] == "self-spawn"
     cfg = line["config"]
@@ -87,7 +100,7 @@ def test_bench_shard_frames_two_ranks_strong_scaling_line():
     assert abs(line["value"] - 128 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-2 * line["value"]
     assert line["roofline"]["frames_per_launch"] == 64           # rank 0's GEMM launches process its own half
     one = subprocess.run(base + ["--gpus", "1"], env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert one.returncode == 0, one.stderr[-3000:]
+    _ok(one, "bench_unsharded_128")
     l1 = [l for l in _json_lines(one.stdout) if "metric" in l][0]
     assert l1["scaling"] == "weak" and l1["config"]["workload"].startswith("custom:") and "T=128" in l1["config"]["workload"]
     assert l1["roofline"]["frames_per_launch"] == 128
@@ -102,7 +115,7 @@ def test_bench_under_torch_distributed_run():
                             "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n),
                             "--frames", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pruned", "--no-720p"] + extra,
                            env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-3000:]
+        _ok(r, "bench_torchrun")
         lines = [l for l in _json_lines(r.stdout) if "metric" in l]
         assert len(lines) == 1, r.stdout[-2000:]
         line = lines[0]
@@ -283,7 +296,7 @@ def test_train_cli_from_feature_cache_with_resume(tmp_path):
                         "gradient_accumulation_steps=2, save_steps=1, seed=5)\n"
                         "tt.train(cfg, tt.FeatureCacheDataset(%r), resume=False, stop_after=2)\n" % (ROOT, b, root)],
                        env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    _ok(r, "train_cli_2ranks")
     lb = _run_train_cli(common + ["--output-dir", b])
     assert [l["step"] for l in lb] == [3]
     sa = tio.load_selector_safetensors(os.path.join(a, "checkpoint-3", "model.safetensors"))
@@ -341,7 +354,7 @@ def test_bench_line_explains_itself_and_times_the_dp_path():
     micro-step, two micro-steps, the bucket all-reduce really issued on a live one-rank RCCL group) with its launch count."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                         "--no-pruned", "--no-720p"], env=_clean_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    _ok(r, "bench_default_line")
     line = [l for l in _json_lines(r.stdout) if "metric" in l][0]
     assert line["ms_per_step_min"] <= line["ms_per_step_median"] <= line["ms_per_step_max"]
     assert abs(line["ms_per_step_median"] - line["ms_per_step"]) < 0.2 * line["ms_per_step"]

@@ -45,13 +45,29 @@ def launched_by_torchrun() -> bool:
     return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
+_RENDEZVOUS_ERRORS = ("address already in use", "eaddrinuse", "connection refused", "failed to connect", "connect() timed out",
+                      "the server socket has failed to listen", "the client socket has failed to connect")
+
+
 def self_spawn(n: int, argv: Sequence[str], module: "str | None" = None, timeout: "float | None" = None) -> int:
+    """`_self_spawn_once`, started again ONCE on a fresh port when the first attempt dies of a rendezvous error (the free port is
+    found by binding and releasing it; another process can take it in between - rare, but a launcher should not fail a job on it).
+    Anything else - a rank's own error, a timeout - is returned as it is."""
+    import sys
+    rc, tail = _self_spawn_once(n, argv, module, timeout)
+    if rc not in (0, 124) and any(m in tail.lower() for m in _RENDEZVOUS_ERRORS):
+        sys.stderr.write(f"self_spawn: rendezvous failed (exit code {rc}); starting the {n} ranks once more on a new port\n")
+        rc, tail = _self_spawn_once(n, argv, module, timeout)
+    return rc
+
+
+def _self_spawn_once(n: int, argv: Sequence[str], module: "str | None" = None, timeout: "float | None" = None):
     """Start `n` ranks of this program on this node without torch.distributed.run (one process per GPU; what
     `train_deepspeed.sh:14-16`'s `torchrun --nproc_per_node` does): `python <argv[0]> <argv[1:]>` (or `python -m module
     <argv[1:]>`) n times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, a free rendezvous port and
     the dmabuf IPC mode RCCL needs.  Children inherit stdout (rank 0 prints the result line); their stderr is forwarded live
     with a `[rank r]` prefix.  Returns the first non-zero exit code (the other ranks are terminated by PID as soon as one rank
-    fails - also when the launcher itself is interrupted), else 0."""
+    fails - also when the launcher itself is interrupted), else 0 - and the kept stderr lines of all ranks (for self_spawn's retry rule)."""
     import collections
     import subprocess
     import sys
@@ -114,7 +130,8 @@ def self_spawn(n: int, argv: Sequence[str], module: "str | None" = None, timeout
         who = f"rank {failed}" if failed is not None else f"timeout after {timeout} s"
         tail = "".join(list(tails[failed])[-12:]) if failed is not None else ""
         sys.stderr.write(f"self_spawn: {who} of {n} exited with code {rc}; the other ranks were stopped.  Last lines of its stderr:\n{tail}")
-    return rc
+        return rc, "".join("".join(t) for t in tails)
+    return rc, ""
 
 
 def shard_prompts(n_global: int, world: int, rank: int) -> range:
