@@ -872,6 +872,13 @@ def main():
     if os.environ.get("TSPO_RCCL_LOG_DIR"):      # this process's RCCL debug files (summarised into `comm` above)
         import shutil
         shutil.rmtree(os.environ["TSPO_RCCL_LOG_DIR"], ignore_errors=True)
+    if world > 1:
+        # every number is printed and the process group is destroyed: leave WITHOUT running the interpreter's / the collective
+        # libraries' static destructors - with several ranks (and, in dry runs, several ranks on ONE device) their order against the
+        # HIP runtime's own teardown is not defined, and a crash there would turn a finished measurement into a failed launch
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
