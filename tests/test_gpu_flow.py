@@ -58,6 +58,72 @@ def test_from_pretrained_roundtrip_forward_on_gpu(tmp_path):
     assert ids1.dtype == torch.int64 and pred1.dtype == torch.bfloat16 and pred1.shape == (72,)
 
 
+class _FakeVideo:
+    """decord.VideoReader stand-in: n frames of 120x160 RGB at 30 fps, frame i a pure function of (seed, i)."""
+
+    def __init__(self, n, seed):
+        self.n, self.seed = n, seed
+
+    def __len__(self):
+        return self.n
+
+    def get_avg_fps(self):
+        return 30.0
+
+    def get_batch(self, idx):
+        arr = np.stack([synth.uniform_u8((120, 160, 3), self.seed * 100003 + int(i)) for i in idx])
+
+        class _B:
+            def asnumpy(self_inner):
+                return arr
+        return _B()
+
+
+@pytest.mark.parametrize("dataset", ["MLVU", "VideoMME"])
+def test_reproduce_published_idx_flow_round_trip(tmp_path, dataset):
+    """tools/reproduce_published_idx.py `run()` - the one command from local weights + videos to the comparison with a published
+    frame list - end to end on the GPU with what this image CAN provide: a small random TSPOModel checkpoint (save_pretrained),
+    the stub processor, an in-memory video reader, and a fake reference checkout holding the annotation docs.  Pass 1 produces the
+    frame-index JSON (feature-cache misses); it is then installed as the 'published' file and pass 2 reproduces it from the caches:
+    exact match on every doc, the >64-candidate docs selected (top-k / bin-max), the short one listing all its candidates."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    spec = importlib.util.spec_from_file_location("reproduce_published_idx", os.path.join(root, "tools", "reproduce_published_idx.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    fname, key, video_of = tool.ANNO[dataset]
+    ref = tmp_path / "ref"
+    (ref / "evaluation" / "jsons").mkdir(parents=True)
+    (ref / "evaluation" / "jsons_idx").mkdir(parents=True)
+    mk = (lambda i, q: {"question_id": f"Q{i}", "video_name": f"v{i}.mp4", "question": q + "\n(A) yes\n(B) no", "answer": "A"}) if dataset == "MLVU" \
+        else (lambda i, q: {"question_id": f"00{i}-1", "videoID": f"v{i}", "question": q, "options": ["A. yes", "B. no"], "answer": "A"})
+    docs = [mk(0, "what happens first?"), mk(1, "who enters the room?"), mk(2, "is it short?")]
+    json.dump(docs, open(ref / "evaluation" / "jsons" / fname, "w"))
+    json.dump([], open(ref / "evaluation" / "jsons_idx" / f"TSPO_{dataset}_frameIdx.json", "w"))
+    lengths = {"v0.mp4": 30 * 90, "v1.mp4": 30 * 70, "v2.mp4": 30 * 40}           # 90 / 70 / 40 one-fps candidates
+    opened = []
+
+    def open_video(path):
+        opened.append(os.path.basename(path))
+        return _FakeVideo(lengths[os.path.basename(path)], len(os.path.basename(path)) + int(os.path.basename(path)[1]))
+    _tiny_model().to(torch.bfloat16).save_pretrained(str(tmp_path / "w"))
+    kw = dict(dataset=dataset, weights=str(tmp_path / "w"), videos=str(tmp_path / "videos"), reference=str(ref),
+              save_root=str(tmp_path / "feats"), processor=_StubProcessor(), open_video=open_video)
+    s1 = tool.run(out=str(tmp_path / "pass1.json"), **kw)
+    assert s1["cache_misses"] == 3 and s1["cache_hits"] == 0 and s1["docs_compared"] == 0 and len(opened) == 3
+    produced = json.load(open(tmp_path / "pass1.json"))
+    by = {d[key]: d["frame_idx"] for d in produced}
+    k0, k1, k2 = (d[key] for d in docs)
+    assert len(by[k0]) == 64 and len(by[k1]) == 64 and by[k2] == [float(30 * i) for i in range(40)]      # T <= 64: every candidate
+    assert all(b > a for a, b in zip(by[k0], by[k0][1:])) and all(v % 30 == 0 for v in by[k0])
+    os.replace(tmp_path / "pass1.json", ref / "evaluation" / "jsons_idx" / f"TSPO_{dataset}_frameIdx.json")
+    s2 = tool.run(out=str(tmp_path / "pass2.json"), **kw)
+    assert s2["cache_hits"] == 3 and len(opened) == 3, "the second pass must come from the feature caches"
+    assert s2["docs_compared"] == 3 and s2["exact_match_rate"] == 1.0 and s2["missing_in_produced"] == 0 and s2["mean_jaccard"] == 1.0
+
+
 @pytest.mark.parametrize("dataset", ["VideoMME", "MLVU"])
 def test_generate_inner_flow_cache_miss_and_hit(tmp_path, dataset):
     """mp_tools/vlmeval/vlm/gen_id_tspo.py:59-92 with the real HIP TSPOModel (bf16, as the harness loads it): miss ->

@@ -17,9 +17,10 @@ What runs, in the reference's order (mp_tools/vlmeval/vlm/gen_id_tspo.py:51-92, 
 Exit code 0 and one JSON summary line (exact-match docs, mean Jaccard, within-one-step overlap).
 
 The `problem` string the agent sees is the annotation's question up to its options, which is what gen_id_tspo.py:64 cuts out of
-the harness's prompt ("Question: ...\nOptions ...").  NOT verified offline: this image holds no weights, videos or decord, so the
-script's model / video branch has never run here; its pieces - the generate_inner flow, the cache and JSON formats, the frame
-plans, the comparison - are what tests/test_gpu_flow.py, tests/test_published_frame_idx.py and tests/test_glue_golden.py pin."""
+the harness's prompt ("Question: ...\nOptions ...").  What IS verified here: `run()` end to end on the GPU with a small random
+TSPOModel checkpoint written by save_pretrained, a stub processor and an in-memory video reader
+(tests/test_gpu_flow.py::test_reproduce_published_idx_flow_round_trip: produce -> publish -> reproduce = exact match, second pass
+from the feature caches).  What is NOT: the real checkpoint, real videos and decord - none of them is in this image."""
 from __future__ import annotations
 
 import argparse
@@ -45,6 +46,54 @@ def problem_of(doc: dict) -> str:
     return q.replace("<image>\n", "").replace("Question: ", "").strip()
 
 
+def run(dataset, weights, videos, reference, save_root, out=None, limit=0, sample_num=64, processor=None, open_video=None,
+        published_name=None):
+    """The whole flow; returns compare_frame_idx's summary.  `processor` (default CLIPProcessor.from_pretrained(weights)) and
+    `open_video(path) -> reader with len() / get_avg_fps() / get_batch(idx).asnumpy()` (default decord.VideoReader) are
+    injectable, which is how tests/test_gpu_flow.py runs this flow end to end without the checkpoint's tokenizer files or decord."""
+    import torch
+    from tspo_amd import io as tio
+    from tspo_amd import video as tvideo
+    from tspo_amd.temporal_agent import TSPOModel
+    import compare_frame_idx as cmp
+
+    if open_video is None:
+        try:
+            from decord import VideoReader, cpu
+        except ImportError:
+            sys.exit("decord is not installed (the reference's video reader, requirements.txt); install it next to the videos")
+        open_video = lambda path: VideoReader(path, ctx=cpu(0), num_threads=1)      # noqa: E731
+    if processor is None:
+        from transformers import CLIPProcessor
+        processor = CLIPProcessor.from_pretrained(weights)
+    fname, key, video_of = ANNO[dataset]
+    docs = json.load(open(os.path.join(reference, "evaluation", "jsons", fname)))
+    if limit:
+        docs = docs[:limit]
+    published = json.load(open(os.path.join(reference, "evaluation", "jsons_idx", published_name or f"TSPO_{dataset}_frameIdx.json")))
+    model = TSPOModel.from_pretrained(weights, torch_dtype=torch.bfloat16).to("cuda").eval()      # gen_id_tspo.py:55
+
+    def load_video(path, max_frames_num=50000, fps=1, force_sample=False):
+        vr = open_video(path)
+        plan = tvideo.plan_uniform(len(vr), vr.get_avg_fps(), fps, max_frames_num, force_sample)
+        return tvideo.load_frames(vr, plan), plan.frame_time, plan.video_time, torch.tensor(plan.frame_idx)
+
+    gen = tio.FrameIdGenerator(model, processor, save_root, sample_num=sample_num, load_video=load_video)
+    results = {}
+    for i, d in enumerate(docs):
+        msg = [{"type": "video", "value": os.path.join(videos, video_of(d))},
+               {"type": "text", "value": "Question: " + problem_of(d) + "\nOptions"}]
+        results[d[key]] = gen.generate_inner(msg, index=d[key], dataset=dataset)
+        if (i + 1) % 25 == 0:
+            print(f"  {i + 1}/{len(docs)} docs ({gen.cache_hits} cache hits)", file=sys.stderr, flush=True)
+    out = out or os.path.join("work_dir", f"tspo_amd_{dataset}_frameIdx.json")
+    tio.write_frame_idx_json(docs, results, out, key=key)
+    pub = [d for d in published if d[key] in results]
+    summary = cmp.compare(json.load(open(out)), pub, key=key)
+    summary.update(out=out, cache_hits=gen.cache_hits, cache_misses=gen.cache_misses)
+    return summary
+
+
 def main() -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--dataset", required=True, choices=sorted(ANNO))
@@ -56,45 +105,10 @@ def main() -> int:
     ap.add_argument("--limit", type=int, default=0, help="first N docs only (0 = all)")
     ap.add_argument("--sample-num", type=int, default=64)
     a = ap.parse_args()
-
     import torch
     if not torch.cuda.is_available():
         sys.exit("needs an MI355X: the product has no CPU path")
-    try:
-        from decord import VideoReader, cpu
-    except ImportError:
-        sys.exit("decord is not installed (the reference's video reader, requirements.txt); install it next to the videos")
-    from transformers import CLIPProcessor
-    from tspo_amd import io as tio
-    from tspo_amd import video as tvideo
-    from tspo_amd.temporal_agent import TSPOModel
-    import compare_frame_idx as cmp
-
-    fname, key, video_of = ANNO[a.dataset]
-    docs = json.load(open(os.path.join(a.reference, "evaluation", "jsons", fname)))
-    if a.limit:
-        docs = docs[: a.limit]
-    published = json.load(open(os.path.join(a.reference, "evaluation", "jsons_idx", f"TSPO_{a.dataset}_frameIdx.json")))
-    model = TSPOModel.from_pretrained(a.weights, torch_dtype=torch.bfloat16).to("cuda").eval()      # gen_id_tspo.py:55
-    processor = CLIPProcessor.from_pretrained(a.weights)
-
-    def load_video(path, max_frames_num=50000, fps=1, force_sample=False):
-        vr = VideoReader(path, ctx=cpu(0), num_threads=1)
-        plan = tvideo.plan_uniform(len(vr), vr.get_avg_fps(), fps, max_frames_num, force_sample)
-        return tvideo.load_frames(vr, plan), plan.frame_time, plan.video_time, torch.tensor(plan.frame_idx)
-
-    gen = tio.FrameIdGenerator(model, processor, a.save_root, sample_num=a.sample_num, load_video=load_video)
-    results = {}
-    for i, d in enumerate(docs):
-        msg = [{"type": "video", "value": os.path.join(a.videos, video_of(d))},
-               {"type": "text", "value": "Question: " + problem_of(d) + "\nOptions"}]
-        results[d[key]] = gen.generate_inner(msg, index=d[key], dataset=a.dataset)
-        if (i + 1) % 25 == 0:
-            print(f"  {i + 1}/{len(docs)} docs ({gen.cache_hits} cache hits)", file=sys.stderr, flush=True)
-    out = a.out or os.path.join("work_dir", f"tspo_amd_{a.dataset}_frameIdx.json")
-    tio.write_frame_idx_json(docs, results, out, key=key)
-    pub = [d for d in published if d[key] in results]
-    summary = cmp.compare(json.load(open(out)), pub, key=key)
+    summary = run(a.dataset, a.weights, a.videos, a.reference, a.save_root, a.out, a.limit, a.sample_num)
     print(json.dumps(summary))
     return 1 if (summary["missing_in_produced"] or summary["extra_in_produced"]) else 0
 
