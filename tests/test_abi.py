@@ -206,3 +206,23 @@ def test_build_names_the_validated_toolchain():
     assert "not the validated" in b.toolchain_note("/bin/echo", [])
     ident = b.lib_identity()
     assert ident["mode"] == "product" and len(ident["src_sha256"]) == 64 and len(ident["lib_sha256"]) == 64
+
+
+def test_option_flags_of_the_header_match_the_binding():
+    """The option words of the `_ex` entries are plain #defines in include/tspo_hip.h; the ctypes side (tspo_amd/ops.py, _lib.py)
+    restates them - they must agree (round 6 added TSPO_SEL_BF16)."""
+    import re
+    from tspo_amd import _lib, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "tspo_hip.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(TSPO_[A-Z0-9_]+)\s+(\d+|0x[0-9a-fA-F]+)\s*$", hdr, flags=re.M)}
+    assert defs["TSPO_SEL_BF16X3"] == ops.SEL_BF16X3 and defs["TSPO_SEL_ACCUMULATE"] == ops.SEL_ACCUMULATE and defs["TSPO_SEL_BF16"] == ops.SEL_BF16
+    assert len({ops.SEL_BF16X3, ops.SEL_ACCUMULATE, ops.SEL_BF16}) == 3 and (ops.SEL_BF16X3 | ops.SEL_ACCUMULATE | ops.SEL_BF16) == 7
+    for name in ("TSPO_CLIP_NO_LN_FOLD", "TSPO_CLIP_PRUNE_LAST", "TSPO_CLIP_FOLD_CACHED"):
+        assert defs[name] == getattr(_lib, name), name
+    assert ops._sel_flags("bf16", forward=True) == defs["TSPO_SEL_BF16"]
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        ops._sel_flags("bf16")                      # the backward calls do not take it
+    with _pt.raises(ValueError):
+        ops._sel_flags("bf16", accumulate=True)
